@@ -1,0 +1,279 @@
+"""CPU oracle for the signature-GAN hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, not the product: only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import it.  Nothing under
+``signature-gan_amd/`` imports, links or executes anything in ``oracle/``.
+
+It is an independent CPU restatement (fp32, torch-CPU functional ops) of the algorithm the
+reference runs on its G+D train-step / generation path.  The arithmetic of the reference
+lives in PyTorch itself (``requirements.txt:5`` pins only ``torch>=2.0.0``), so the oracle is
+"this restatement x torch CPU"; it is PINNED against outputs of the reference itself, produced
+in the build container by importing ``/root/reference/src`` (``tests/golden/make_golden.py``,
+fixtures committed under ``tests/golden/``; torch version recorded in every fixture).
+
+Reference lines followed (all under /root/reference/src):
+  * Generator  : generator_vanilla_gan.py:124-163 (layers), :189-209 (forward)
+  * Discriminator: discriminator_vanilla_gan.py:51-75 (block), :131-207 (layers), :241-274
+  * BCE / labels / D step / G step: vanilla_gan_model.py:107, :152-178, :180-252, :254-306
+  * clipping + trainer variants of the steps: train_vanilla_gan_signatures.py:262-376
+  * Adam hyper-parameters: vanilla_gan_model.py:110-120 (torch.optim.Adam defaults otherwise)
+
+State is held in plain dicts keyed exactly like the reference's ``state_dict()``.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+BN_MOMENTUM = 0.1   # torch.nn.BatchNorm default (generator_vanilla_gan.py:58,126 use defaults)
+BN_EPS = 1e-5
+ADAM_EPS = 1e-8     # torch.optim.Adam default (vanilla_gan_model.py:110-120 pass lr/betas only)
+
+# generator_vanilla_gan.py:131-149 -- channel chain of the ConvTranspose2d blocks
+G_CHAIN = {64: (256, 128, 64, 32, 32), 128: (512, 256, 128, 64, 32, 32)}
+# discriminator_vanilla_gan.py:131-194 -- channel chain of the Conv2d blocks
+D_CHAIN = {64: (64, 128, 256, 512), 128: (64, 128, 256, 512, 512)}
+
+
+# --------------------------------------------------------------------------------------
+# layouts (names/shapes in parameters() / state_dict() order)
+# --------------------------------------------------------------------------------------
+def g_state_specs(latent_dim: int, size: int, channels: int = 1) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """state_dict entries of Generator: name -> (shape, kind) with kind in
+    {'param','buffer','counter'} (generator_vanilla_gan.py:124-163)."""
+    if size not in G_CHAIN:
+        raise ValueError(f"output_size must be 64 or 128, got {size}")   # :106-107
+    chain = G_CHAIN[size]
+    feat = chain[0] * 16
+    s: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+    s["fc.0.weight"] = ((feat, latent_dim), "param")
+    s["fc.0.bias"] = ((feat,), "param")
+    s["fc.1.weight"] = ((feat,), "param")
+    s["fc.1.bias"] = ((feat,), "param")
+    s["fc.1.running_mean"] = ((feat,), "buffer")
+    s["fc.1.running_var"] = ((feat,), "buffer")
+    s["fc.1.num_batches_tracked"] = ((), "counter")
+    for i in range(len(chain) - 1):
+        cin, cout = chain[i], chain[i + 1]
+        p = f"upsample_blocks.{i}.block."
+        s[p + "0.weight"] = ((cin, cout, 4, 4), "param")       # ConvTranspose2d layout (in,out,kh,kw)
+        s[p + "1.weight"] = ((cout,), "param")
+        s[p + "1.bias"] = ((cout,), "param")
+        s[p + "1.running_mean"] = ((cout,), "buffer")
+        s[p + "1.running_var"] = ((cout,), "buffer")
+        s[p + "1.num_batches_tracked"] = ((), "counter")
+    s["final_conv.0.weight"] = ((channels, chain[-1], 3, 3), "param")
+    s["final_conv.0.bias"] = ((channels,), "param")
+    return s
+
+
+def d_state_specs(size: int, channels: int = 1) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """state_dict entries of Discriminator (discriminator_vanilla_gan.py:131-207)."""
+    if size not in D_CHAIN:
+        raise ValueError(f"input_size must be 64 or 128, got {size}")    # :121-122
+    chain = (channels,) + D_CHAIN[size]
+    s: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+    for i in range(len(chain) - 1):
+        p = f"conv_blocks.{i}.block.0."
+        s[p + "weight"] = ((chain[i + 1], chain[i], 4, 4), "param")
+        s[p + "bias"] = ((chain[i + 1],), "param")
+    s["classifier.0.weight"] = ((1, chain[-1] * 16), "param")
+    s["classifier.0.bias"] = ((1,), "param")
+    return s
+
+
+def param_names(specs) -> List[str]:
+    return [k for k, (_, kind) in specs.items() if kind == "param"]
+
+
+# --------------------------------------------------------------------------------------
+# forward passes
+# --------------------------------------------------------------------------------------
+def g_forward(sd: Dict[str, Tensor], z: Tensor, training: bool, size: int) -> Tensor:
+    """Generator.forward (generator_vanilla_gan.py:189-209).  ``training`` selects the
+    BatchNorm mode; in training mode running stats / num_batches_tracked in ``sd`` are
+    updated in place exactly as nn.BatchNorm does (momentum 0.1, unbiased running var)."""
+    chain = G_CHAIN[size]
+
+    def bn(x, prefix):
+        if training:
+            sd[prefix + "num_batches_tracked"] += 1
+        return F.batch_norm(x, sd[prefix + "running_mean"], sd[prefix + "running_var"],
+                            sd[prefix + "weight"], sd[prefix + "bias"],
+                            training, BN_MOMENTUM, BN_EPS)
+
+    x = F.linear(z, sd["fc.0.weight"], sd["fc.0.bias"])
+    x = F.relu(bn(x, "fc.1."))
+    x = x.view(-1, chain[0], 4, 4)
+    for i in range(len(chain) - 1):
+        p = f"upsample_blocks.{i}.block."
+        x = F.conv_transpose2d(x, sd[p + "0.weight"], None, stride=2, padding=1)
+        x = F.relu(bn(x, p + "1."))
+    x = F.conv2d(x, sd["final_conv.0.weight"], sd["final_conv.0.bias"], stride=1, padding=1)
+    return torch.tanh(x)
+
+
+def d_features(sd: Dict[str, Tensor], x: Tensor, size: int,
+               masks: Optional[Sequence[Tensor]] = None,
+               dropout: float = 0.25, slope: float = 0.2) -> Tensor:
+    """Discriminator.forward_features (discriminator_vanilla_gan.py:262-274).  ``masks`` is a
+    list of (B, C_i) keep masks (1 keep / 0 drop), one per block, standing in for the hidden
+    RNG of nn.Dropout2d (:74-75); None means eval mode (dropout off)."""
+    n_blocks = len(D_CHAIN[size])
+    for i in range(n_blocks):
+        p = f"conv_blocks.{i}.block.0."
+        x = F.conv2d(x, sd[p + "weight"], sd[p + "bias"], stride=2, padding=1)
+        x = F.leaky_relu(x, slope)
+        if masks is not None and dropout > 0:
+            noise = masks[i].to(x.dtype) / (1.0 - dropout)     # bernoulli(1-p).div_(1-p)
+            x = x * noise[:, :, None, None]
+    return x.flatten(1)
+
+
+def d_forward(sd, x, size, masks=None, dropout=0.25, slope=0.2) -> Tensor:
+    """Discriminator.forward (:241-260): probabilities (B,1)."""
+    f = d_features(sd, x, size, masks, dropout, slope)
+    return torch.sigmoid(F.linear(f, sd["classifier.0.weight"], sd["classifier.0.bias"]))
+
+
+def bce(p: Tensor, y: float) -> Tensor:
+    """nn.BCELoss(reduction='mean') on probabilities (vanilla_gan_model.py:107): log terms
+    clamped at -100 (torch semantics)."""
+    t = torch.full_like(p, y)
+    return -(t * torch.clamp(torch.log(p), min=-100.0)
+             + (1.0 - t) * torch.clamp(torch.log(1.0 - p), min=-100.0)).mean()
+
+
+# --------------------------------------------------------------------------------------
+# optimiser pieces
+# --------------------------------------------------------------------------------------
+def clip_grad_norm(grads: Sequence[Tensor], max_norm: float) -> float:
+    """nn.utils.clip_grad_norm_ (train_vanilla_gan_signatures.py:275-278): global L2 norm,
+    scale by min(1, max_norm/(norm+1e-6)); returns the pre-clip norm."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g, 2.0) for g in grads]), 2.0)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return float(total)
+
+
+def adam_update(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int,
+                lr: float, beta1: float, beta2: float, eps: float = ADAM_EPS) -> None:
+    """One torch.optim.Adam update (single-tensor form, weight_decay 0, amsgrad False);
+    ``step`` is the step count AFTER the increment.  In place on p, m, v."""
+    m.lerp_(g, 1.0 - beta1)                                  # m = b1*m + (1-b1)*g
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    step_size = lr / bc1
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-step_size)
+
+
+class AdamState:
+    """exp_avg / exp_avg_sq / step per parameter, in parameters() order."""
+
+    def __init__(self, names: Sequence[str], sd: Dict[str, Tensor]):
+        self.names = list(names)
+        self.m = {k: torch.zeros_like(sd[k]) for k in self.names}
+        self.v = {k: torch.zeros_like(sd[k]) for k in self.names}
+        self.step = 0
+
+    def apply(self, sd, grads: Dict[str, Tensor], lr, beta1, beta2):
+        self.step += 1
+        for k in self.names:
+            adam_update(sd[k], grads[k], self.m[k], self.v[k], self.step, lr, beta1, beta2)
+
+
+# --------------------------------------------------------------------------------------
+# the two training steps
+# --------------------------------------------------------------------------------------
+def _leafs(sd, names):
+    return {k: sd[k].detach().clone().requires_grad_(True) for k in names}
+
+
+def d_grads(g_sd, d_sd, real: Tensor, z: Tensor, masks_real, masks_fake, size: int,
+            label_smoothing: float = 0.9, dropout: float = 0.25):
+    """Forward/backward half of the D step (vanilla_gan_model.py:204-233 ==
+    train_vanilla_gan_signatures.py:294-323): returns (metrics, grads, real_preds, fake_preds,
+    fake_images).  G runs in eval mode under no_grad; only D parameters receive gradients."""
+    names = param_names(d_state_specs(size, real.shape[1]))
+    leaf = _leafs(d_sd, names)
+    with torch.no_grad():
+        fake = g_forward(g_sd, z, training=False, size=size)
+    real_preds = d_forward(leaf, real, size, masks_real, dropout)
+    loss_real = bce(real_preds, label_smoothing)
+    fake_preds = d_forward(leaf, fake, size, masks_fake, dropout)
+    loss_fake = bce(fake_preds, 0.0)
+    loss = loss_real + loss_fake
+    gl = torch.autograd.grad(loss, [leaf[k] for k in names])
+    grads = {k: g.detach() for k, g in zip(names, gl)}
+    loss, loss_real, loss_fake = loss.detach(), loss_real.detach(), loss_fake.detach()
+    real_preds, fake_preds = real_preds.detach(), fake_preds.detach()
+    metrics = {
+        "d_loss": float(loss), "d_loss_real": float(loss_real), "d_loss_fake": float(loss_fake),
+        "d_real_mean": float(real_preds.mean()), "d_fake_mean": float(fake_preds.mean()),
+        "d_real_acc": float((real_preds > 0.5).float().mean()),
+        "d_fake_acc": float((fake_preds < 0.5).float().mean()),
+    }
+    return metrics, grads, real_preds.detach(), fake_preds.detach(), fake
+
+
+def g_grads(g_sd, d_sd, z: Tensor, size: int):
+    """Forward/backward half of the G step (vanilla_gan_model.py:274-297 ==
+    train_vanilla_gan_signatures.py:349-365): G in train mode (BN batch statistics, running
+    stats updated in ``g_sd``), D in eval mode (dropout off), BCE against 1.0 (no smoothing)."""
+    names = param_names(g_state_specs(z.shape[1], size))
+    leaf = dict(g_sd)
+    leaf.update(_leafs(g_sd, names))
+    fake = g_forward(leaf, z, training=True, size=size)
+    for k in g_sd:                      # running stats / counters were updated on the copies
+        if k not in names:
+            g_sd[k] = leaf[k]
+    fake_preds = d_forward(d_sd, fake, size, None)
+    loss = bce(fake_preds, 1.0)
+    gl = torch.autograd.grad(loss, [leaf[k] for k in names])
+    grads = {k: g.detach() for k, g in zip(names, gl)}
+    loss, fake_preds = loss.detach(), fake_preds.detach()
+    metrics = {"g_loss": float(loss), "g_fake_mean": float(fake_preds.mean())}
+    return metrics, grads, fake_preds.detach(), fake.detach()
+
+
+def d_step(g_sd, d_sd, d_opt: AdamState, real, z, masks_real, masks_fake, size,
+           lr=2e-4, beta1=0.5, beta2=0.999, label_smoothing=0.9, clip: Optional[float] = None,
+           dropout: float = 0.25):
+    metrics, grads, rp, fp, fake = d_grads(g_sd, d_sd, real, z, masks_real, masks_fake, size,
+                                           label_smoothing, dropout)
+    metrics["d_grad_norm"] = clip_grad_norm(list(grads.values()), clip) if clip is not None else None
+    d_opt.apply(d_sd, grads, lr, beta1, beta2)
+    return metrics, grads
+
+
+def g_step(g_sd, d_sd, g_opt: AdamState, z, size, lr=2e-4, beta1=0.5, beta2=0.999,
+           clip: Optional[float] = None):
+    metrics, grads, fp, fake = g_grads(g_sd, d_sd, z, size)
+    metrics["g_grad_norm"] = clip_grad_norm(list(grads.values()), clip) if clip is not None else None
+    g_opt.apply(g_sd, grads, lr, beta1, beta2)
+    return metrics, grads
+
+
+def average_grads(per_rank: Sequence[Dict[str, Tensor]]) -> Dict[str, Tensor]:
+    """Data-parallel emulation: mean of the replicas' gradients."""
+    out = {}
+    for k in per_rank[0]:
+        out[k] = torch.stack([g[k] for g in per_rank]).mean(0)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# image post-processing used by the generation callers (utils/inference.py:106-134)
+# --------------------------------------------------------------------------------------
+def to_uint8(img: Tensor) -> Tensor:
+    """((x + 1) * 127.5).clip(0, 255).astype(uint8) -- truncation, not rounding."""
+    return ((img + 1.0) * 127.5).clamp(0, 255).to(torch.uint8)

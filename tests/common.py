@@ -1,0 +1,66 @@
+"""Shared helpers for the parity tests: build oracle-side states from the synthetic inputs and
+read the golden fixtures (outputs of the reference, see tests/golden/make_golden.py)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, os.path.join(HERE, "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import inputs as I                                   # noqa: E402  (tests/golden/inputs.py)
+from oracle import siggan_oracle as O                # noqa: E402  (the checker)
+
+GOLDEN = os.path.join(HERE, "golden")
+CASES = [(64, 100, 4), (64, 100, 64), (128, 128, 4), (128, 128, 32)]
+SEED = dict(state_g=101, state_d=202, adam_g=303, adam_d=404, z=11, real=22)
+
+
+def load_golden(size, batch):
+    f = np.load(os.path.join(GOLDEN, f"golden_s{size}_b{batch}.npz"))
+    meta = json.loads(str(f["meta"]))
+    return f, meta
+
+
+def d_chans(size):
+    return list(O.D_CHAIN[size])
+
+
+def oracle_states(size, latent, warm):
+    gs, ds = O.g_state_specs(latent, size), O.d_state_specs(size)
+    g_sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in I.gen_state(gs, SEED["state_g"]).items()}
+    d_sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in I.gen_state(ds, SEED["state_d"]).items()}
+    g_opt, d_opt = O.AdamState(O.param_names(gs), g_sd), O.AdamState(O.param_names(ds), d_sd)
+    if warm:
+        for opt, specs, seed in ((g_opt, gs, SEED["adam_g"]), (d_opt, ds, SEED["adam_d"])):
+            m, v, step = I.gen_adam(specs, seed)
+            opt.m = {k: torch.from_numpy(a).clone() for k, a in m.items()}
+            opt.v = {k: torch.from_numpy(a).clone() for k, a in v.items()}
+            opt.step = step
+    return g_sd, d_sd, g_opt, d_opt
+
+
+def masks_from(f, key, batch, size, passes):
+    chans = d_chans(size) * passes
+    ms = I.unpack_masks(f[key], batch, chans)
+    return [torch.from_numpy(m) for m in ms]
+
+
+def probe(t, name):
+    a = t.detach().reshape(-1).cpu().numpy()
+    return a[I.probe_idx(a.size, name)]
+
+
+def assert_close(got, want, rtol, atol, what):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    if not np.all(err <= tol):
+        i = int(np.argmax(err - tol))
+        raise AssertionError(f"{what}: max violation at {i}: got {got.flat[i]!r} want {want.flat[i]!r} "
+                             f"(err {err.flat[i]:.3e}, tol {tol.flat[i]:.3e}); max err {err.max():.3e}")

@@ -1,0 +1,128 @@
+"""Pin the oracle (oracle/siggan_oracle.py) against the reference's own outputs (golden fixtures).
+
+CPU only.  Tolerances: fp32, rtol 1e-4 / small atol -- the oracle and the reference run the same
+torch CPU kernels, so they normally agree to ~1e-6; Adam second-moment probes are tiny numbers
+(1e-6 scale) and use a relative test."""
+import numpy as np
+import pytest
+import torch
+
+from common import CASES, I, O, SEED, assert_close, load_golden, masks_from, oracle_states, probe
+
+RT, AT = 1e-4, 1e-6
+
+
+@pytest.mark.parametrize("size,latent,batch", CASES)
+def test_forward_passes(size, latent, batch):
+    f, meta = load_golden(size, batch)
+    z = torch.from_numpy(I.gen_z(batch, latent, SEED["z"]))
+    real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
+    g_sd, d_sd, _, _ = oracle_states(size, latent, warm=False)
+
+    img = O.g_forward(g_sd, z, False, size)
+    if "g_eval/img" in f:
+        assert_close(img.numpy(), f["g_eval/img"], RT, AT, "g_eval image")
+    flat = img.reshape(-1).numpy()
+    assert_close(flat[I.probe_idx(flat.size, "img", 256)], f["g_eval/probe"], RT, AT, "g_eval probe")
+
+    img = O.g_forward(g_sd, z, True, size)
+    flat = img.reshape(-1).numpy()
+    assert_close(flat[I.probe_idx(flat.size, "img", 256)], f["g_train/probe"], RT, AT, "g_train probe")
+    for k in g_sd:
+        if "running" in k or "num_batches" in k:
+            assert_close(probe(g_sd[k].float(), k), f["g_train/buf/" + k], RT, AT, k)
+
+    g_sd, d_sd, _, _ = oracle_states(size, latent, warm=False)
+    assert_close(O.d_forward(d_sd, real, size).reshape(-1).numpy(), f["d_eval/probs"], RT, AT, "d_eval probs")
+    feat = O.d_features(d_sd, real, size).reshape(-1).numpy()
+    assert_close(feat[I.probe_idx(feat.size, "feat", 256)], f["d_eval/feat_probe"], RT, AT, "d features")
+    masks = masks_from(f, "d_train/masks", batch, size, 1)
+    assert_close(O.d_forward(d_sd, real, size, masks).reshape(-1).numpy(), f["d_train/probs"], RT, AT,
+                 "d_train probs")
+
+
+def _check_step(f, tag, names, metrics, grads, sd, opt, bufs=None):
+    for k, v in metrics.items():
+        key = f"{tag}/metric/{k}"
+        if v is not None and key in f:
+            assert_close(v, f[key], 1e-4, 1e-6, key)
+    gn = np.array([float(grads[k].norm()) for k in names])
+    ref_gn = f[f"{tag}/grad_norm"]
+    gscale = float(max(np.abs(f[f"{tag}/grad/{k}"]).max() for k in names))     # network-wide grad scale
+    assert_close(gn, ref_gn, 1e-3, 1e-4 * float(ref_gn.max()), tag + " grad norms")
+    for k, rn in zip(names, ref_gn):
+        # a parameter whose gradient is mathematically zero (a bias in front of a train-mode
+        # BatchNorm) carries rounding noise only: Adam turns that noise into +-lr-sized moves,
+        # so its moments / weights are checked against that bound, not bit-for-bit.
+        noise = rn < 1e-5 * float(ref_gn.max())
+        assert_close(probe(grads[k], k), f[f"{tag}/grad/{k}"], 1e-3, 1e-4 * gscale, f"{tag} grad {k}")
+        assert_close(probe(opt.m[k], k), f[f"{tag}/m/{k}"], 1e-3, 1e-4 * gscale, f"{tag} exp_avg {k}")
+        assert_close(probe(opt.v[k], k), f[f"{tag}/v/{k}"], 1e-3, 1e-7 * gscale * gscale, f"{tag} exp_avg_sq {k}")
+        assert_close(probe(sd[k], k), f[f"{tag}/w/{k}"], 1e-4, 2.5e-4 if noise else 2e-6, f"{tag} weight {k}")
+    assert float(f[f"{tag}/adam_step"]) == opt.step
+    if bufs:
+        for k in bufs:
+            assert_close(probe(sd[k].float(), k), f[f"{tag}/buf/{k}"], 1e-4, 1e-6, f"{tag} buffer {k}")
+
+
+@pytest.mark.parametrize("size,latent,batch", CASES)
+@pytest.mark.parametrize("tag", ["warm", "fresh", "clip"])
+def test_single_steps(size, latent, batch, tag):
+    f, meta = load_golden(size, batch)
+    clip = meta["clip"] if tag == "clip" else None
+    z = torch.from_numpy(I.gen_z(batch, latent, SEED["z"]))
+    z2 = torch.from_numpy(I.gen_z(batch, latent, SEED["z"] + 1))
+    real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
+
+    g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=(tag != "fresh"))
+    masks = masks_from(f, f"dstep_{tag}/masks", batch, size, 2)
+    nb = len(masks) // 2
+    met, grads = O.d_step(g_sd, d_sd, d_opt, real, z, masks[:nb], masks[nb:], size, clip=clip)
+    if clip is not None:
+        assert met["d_grad_norm"] > clip, "fixture was meant to have clipping active"
+    _check_step(f, f"dstep_{tag}", d_opt.names, met, grads, d_sd, d_opt)
+
+    g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=(tag != "fresh"))
+    met, grads = O.g_step(g_sd, d_sd, g_opt, z2, size, clip=clip)
+    if clip is not None:
+        assert met["g_grad_norm"] > clip
+    bufs = [k for k in g_sd if k not in g_opt.names]
+    _check_step(f, f"gstep_{tag}", g_opt.names, met, grads, g_sd, g_opt, bufs)
+
+
+@pytest.mark.parametrize("size,latent,batch", CASES[:2])
+def test_three_step_sequence(size, latent, batch):
+    """Loss/prediction tolerance only: Adam amplifies rounding-order differences."""
+    f, meta = load_golden(size, batch)
+    real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
+    g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=True)
+    masks = masks_from(f, "seq3/masks", batch, size, 6)
+    nb = len(masks) // 6
+    rows = []
+    for s in range(3):
+        zs = torch.from_numpy(I.gen_z(batch, latent, 1000 + 2 * s))
+        zg = torch.from_numpy(I.gen_z(batch, latent, 1001 + 2 * s))
+        ms = masks[2 * nb * s: 2 * nb * (s + 1)]
+        dm, _ = O.d_step(g_sd, d_sd, d_opt, real, zs, ms[:nb], ms[nb:], size)
+        gm, _ = O.g_step(g_sd, d_sd, g_opt, zg, size)
+        rows.append([dm["d_loss"], dm["d_loss_real"], dm["d_loss_fake"], dm["d_real_mean"],
+                     dm["d_fake_mean"], gm["g_loss"], gm["g_fake_mean"]])
+    assert_close(np.array(rows), f["seq3/metrics"], 1e-3, 1e-4, "3-step metrics")
+
+
+def test_param_counts_match_reference_manifest():
+    import json, os
+    from common import GOLDEN
+    man = json.load(open(os.path.join(GOLDEN, "checkpoint_manifest.json")))
+    for size, latent in ((64, 100), (128, 128)):
+        gs, ds = O.g_state_specs(latent, size), O.d_state_specs(size)
+        n = lambda specs: sum(int(np.prod(s)) for s, kind in specs.values() if kind == "param")
+        assert n(gs) == man[f"s{size}"]["g_params"] and n(ds) == man[f"s{size}"]["d_params"]
+        ref_g = man[f"s{size}"]["layout_A"]["generator_state_dict"]
+        assert list(ref_g) == list(gs)
+        for k, (shape, _) in gs.items():
+            assert ref_g[k]["tensor"] == list(shape), k
+        ref_d = man[f"s{size}"]["layout_A"]["discriminator_state_dict"]
+        assert list(ref_d) == list(ds)
+        for k, (shape, _) in ds.items():
+            assert ref_d[k]["tensor"] == list(shape), k
