@@ -1,0 +1,191 @@
+/*
+ * siggan.h -- C ABI of the MI355X (gfx950) signature-GAN engine.
+ *
+ * The reference (Nobita421/signature-Gan) has no FFI/plugin interface: its G+D train step and
+ * its generation path sit behind Python classes.  This header is the boundary a maintainer
+ * binds (ctypes) to route exactly that path to hand-written HIP kernels:
+ *
+ *   entry point              replaces (file:line under /root/reference/src)
+ *   -----------------------  ---------------------------------------------------------------
+ *   siggan_g_forward         Generator.forward            generator_vanilla_gan.py:189-209
+ *                            (VanillaGAN.generate vanilla_gan_model.py:338-371,
+ *                             generate_signatures_batch utils/inference.py:171-182)
+ *   siggan_d_forward         Discriminator.forward / forward_features
+ *                                                        discriminator_vanilla_gan.py:241-274
+ *   siggan_d_step            VanillaGAN.train_discriminator_step vanilla_gan_model.py:180-252
+ *                            == GANTrainer._train_discriminator  train_vanilla_gan_signatures.py:281-337
+ *   siggan_g_step            VanillaGAN.train_generator_step    vanilla_gan_model.py:254-306
+ *                            == GANTrainer._train_generator     train_vanilla_gan_signatures.py:339-376
+ *   siggan_d_grads/_apply,   the same two steps cut at the point where a data-parallel run
+ *   siggan_g_grads/_apply    averages the flat gradient bucket across ranks (RCCL all-reduce
+ *                            issued by the host between the two halves)
+ *   siggan_op_*              single kernels of the path (operator-level tests / profiling)
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer named *_dev is DEVICE memory of the context's
+ *     GPU, fp32 unless stated; images are (B,1,S,S) contiguous (NCHW == NHWC for one channel).
+ *   - ownership: the CALLER owns every tensor it passes (parameters, gradients, Adam moments,
+ *     BatchNorm buffers, inputs, outputs) and their lifetime; the library owns only its
+ *     workspace.  Parameter storage is BORROWED by siggan_bind: four flat arenas per network
+ *     laid out in the reference's parameters() order, so the torch-side state_dict()/optimizer
+ *     state stay authoritative and checkpoints need no conversion.
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*); no hidden device-wide
+ *     synchronisation except where a HOST output pointer (metrics_host) is given.
+ *   - return value: 0 = OK, negative = SIGGAN_E_*; never throws, never aborts.
+ *     siggan_last_error() returns a thread-local message for the last failure.
+ *   - one context per device per process; a context is not re-entrant.
+ */
+#ifndef SIGGAN_H
+#define SIGGAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIGGAN_ABI_VERSION 1
+
+enum {
+    SIGGAN_OK = 0,
+    SIGGAN_E_INVALID = -1,     /* bad argument (maps to ValueError in the Python shim) */
+    SIGGAN_E_STATE = -2,       /* call sequence / binding missing                      */
+    SIGGAN_E_HIP = -3,         /* HIP runtime error                                    */
+    SIGGAN_E_NOMEM = -4
+};
+
+typedef struct siggan_ctx siggan_ctx;
+
+/* Model geometry: Generator(latent_dim, output_size) / Discriminator(input_size)
+ * (generator_vanilla_gan.py:97-121, discriminator_vanilla_gan.py:111-128). */
+typedef struct siggan_config {
+    int32_t device;         /* HIP device ordinal */
+    int32_t latent_dim;     /* z dimension (reference default 100) */
+    int32_t image_size;     /* 64 or 128 -- anything else is SIGGAN_E_INVALID (ValueError) */
+    int32_t image_channels; /* only 1 (grayscale signatures) is built */
+    int32_t max_batch;      /* largest per-call batch the workspace is sized for */
+    float   dropout;        /* Discriminator dropout p (default 0.25) */
+    float   leaky_slope;    /* LeakyReLU slope (default 0.2) */
+    uint64_t seed;          /* seed of the library's counter-based RNG (z, dropout masks) */
+} siggan_config;
+
+/* Borrowed storage.  *_params / *_grads / *_exp_avg / *_exp_avg_sq: flat fp32 arenas holding
+ * the network's parameters() in reference order (sizes: siggan_param_count).  *_adam_steps: one
+ * fp32 per parameter TENSOR (torch.optim.Adam keeps `step` per tensor).  g_bn_*: BatchNorm
+ * running statistics of all G BatchNorm layers concatenated in module order (fc.1, then
+ * upsample_blocks.i.block.1); g_bn_batches: one int64 per BatchNorm layer. */
+typedef struct siggan_storage {
+    float *g_params, *g_grads, *g_exp_avg, *g_exp_avg_sq, *g_adam_steps;
+    float *g_bn_running_mean, *g_bn_running_var;
+    int64_t *g_bn_batches;
+    float *d_params, *d_grads, *d_exp_avg, *d_exp_avg_sq, *d_adam_steps;
+} siggan_storage;
+
+/* Optimiser / loss hyper-parameters of one step (vanilla_gan_model.py:60-72,
+ * train_vanilla_gan_signatures.py:63-79). */
+typedef struct siggan_hyper {
+    double lr, beta1, beta2, eps; /* Adam, as the Python doubles torch.optim.Adam holds (eps: torch default
+                                   * 1e-8); 1 - beta and the bias corrections are formed in double, as torch does */
+    float label_smoothing;        /* real-label value in the D step (0.9) */
+    float clip_max_norm;          /* <= 0: gradient clipping disabled */
+    float grad_scale;             /* multiplies the gradients before clip/Adam (1/world for DP sums; 1 otherwise) */
+} siggan_hyper;
+
+/* metrics written by the step calls (fp32 each) */
+enum {
+    SIGGAN_M_D_LOSS = 0, SIGGAN_M_D_LOSS_REAL, SIGGAN_M_D_LOSS_FAKE, SIGGAN_M_D_REAL_MEAN,
+    SIGGAN_M_D_FAKE_MEAN, SIGGAN_M_D_REAL_ACC, SIGGAN_M_D_FAKE_ACC, SIGGAN_M_D_GRAD_NORM,
+    SIGGAN_M_G_LOSS, SIGGAN_M_G_FAKE_MEAN, SIGGAN_M_G_GRAD_NORM,
+    SIGGAN_M_COUNT = 16
+};
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int siggan_abi_version(void);
+const char *siggan_last_error(void);
+int siggan_create(const siggan_config *cfg, siggan_ctx **out);
+int siggan_destroy(siggan_ctx *ctx);
+
+/* which: 0 = generator, 1 = discriminator */
+int64_t siggan_param_count(const siggan_ctx *ctx, int which);          /* scalars in the flat arena */
+int32_t siggan_param_tensors(const siggan_ctx *ctx, int which);        /* number of parameter tensors */
+/* offset (in floats) and element count of parameter tensor `idx` inside the flat arena */
+int siggan_param_span(const siggan_ctx *ctx, int which, int32_t idx, int64_t *offset, int64_t *numel);
+int64_t siggan_bn_count(const siggan_ctx *ctx);                        /* floats in g_bn_running_* */
+int32_t siggan_bn_layers(const siggan_ctx *ctx);
+int64_t siggan_workspace_bytes(const siggan_ctx *ctx);
+
+int siggan_bind(siggan_ctx *ctx, const siggan_storage *st);
+/* tell the library the caller changed parameters / BN buffers behind its back
+ * (load_state_dict, manual edits): packed weight copies are rebuilt on next use */
+int siggan_params_changed(siggan_ctx *ctx);
+int siggan_seed(siggan_ctx *ctx, uint64_t seed, uint64_t offset);
+
+/* ---- forward passes ---------------------------------------------------------------------- */
+/* z_dev (B,latent) -> images_dev (B,1,S,S) in [-1,1].  training!=0: BatchNorm batch statistics,
+ * running stats and num_batches_tracked updated (nn.Module.train()); 0: running stats (eval). */
+int siggan_g_forward(siggan_ctx *ctx, const float *z_dev, int32_t batch, int32_t training,
+                     float *images_dev, void *stream);
+
+/* x_dev (B,1,S,S) -> probs_dev (B) probabilities.  features_dev (B,512*4*4, reference
+ * flatten order c,h,w) optional.  training!=0 enables Dropout2d: masks_dev, if given, holds the
+ * keep masks (1 keep / 0 drop) of all blocks concatenated [(B,C_1),(B,C_2),...]; NULL draws
+ * them from the library RNG. */
+int siggan_d_forward(siggan_ctx *ctx, const float *x_dev, int32_t batch, int32_t training,
+                     const float *masks_dev, float *probs_dev, float *features_dev, void *stream);
+
+/* ---- training steps ---------------------------------------------------------------------- */
+/* D step: D(real) vs label_smoothing, G_eval(z) under no-grad, D(fake) vs 0, backward into D,
+ * optional clip, Adam(D).  z_dev NULL: z ~ N(0,1) from the library RNG.  masks_dev NULL: library
+ * RNG; else keep masks for the real pass then the fake pass, each [(B,C_1)...(B,C_n)].
+ * metrics_dev (SIGGAN_M_COUNT floats, optional) receives the metrics on the device;
+ * metrics_host (optional) additionally copies them to the host and synchronises the stream. */
+int siggan_d_step(siggan_ctx *ctx, const float *real_dev, int32_t batch, const float *z_dev,
+                  const float *masks_dev, const siggan_hyper *hp, float *metrics_dev,
+                  float *metrics_host, void *stream);
+/* G step: G_train(z) (BN batch stats + running-stat update), D_eval(fake), BCE vs 1.0, backward
+ * through D into G (D weight gradients are not formed), optional clip, Adam(G). */
+int siggan_g_step(siggan_ctx *ctx, int32_t batch, const float *z_dev, const siggan_hyper *hp,
+                  float *metrics_dev, float *metrics_host, void *stream);
+
+/* data-parallel halves: *_grads leaves the local gradient in the bound *_grads arena (and the
+ * forward metrics in metrics_dev); the host all-reduces the arena; *_apply scales by
+ * hp->grad_scale, clips and runs Adam. */
+int siggan_d_grads(siggan_ctx *ctx, const float *real_dev, int32_t batch, const float *z_dev,
+                   const float *masks_dev, const siggan_hyper *hp, float *metrics_dev, void *stream);
+int siggan_d_apply(siggan_ctx *ctx, const siggan_hyper *hp, float *metrics_dev, float *metrics_host,
+                   void *stream);
+int siggan_g_grads(siggan_ctx *ctx, int32_t batch, const float *z_dev, const siggan_hyper *hp,
+                   float *metrics_dev, void *stream);
+int siggan_g_apply(siggan_ctx *ctx, const siggan_hyper *hp, float *metrics_dev, float *metrics_host,
+                   void *stream);
+
+/* ---- operator-level entry points (tests, profiling) --------------------------------------- */
+/* All tensors NHWC fp32 on the device.  4x4 stride-2 pad-1 convolution family on MFMA:
+ *   form 0 "down": out[n,oh,ow,co] = sum_{kh,kw,ci} in[n,2oh-1+kh,2ow-1+kw,ci] * w[co,ci,kh,kw]
+ *                  (Conv2d forward; ConvTranspose2d input-gradient)            w is (Cout,Cin,4,4)
+ *   form 1 "up"  : out[n,oh,ow,co] = sum_{ci,kh,kw: oh=2ih-1+kh} in[n,ih,iw,ci] * w[ci,co,kh,kw]
+ *                  (ConvTranspose2d forward; Conv2d input-gradient)            w is (Cin,Cout,4,4)
+ * w_dev is in the reference's (torch) layout; the library packs it. */
+int siggan_op_conv4x4s2(siggan_ctx *ctx, int32_t form, const float *in_dev, const float *w_dev,
+                        float *out_dev, int32_t batch, int32_t h_in, int32_t c_in, int32_t c_out,
+                        void *stream);
+/* weight gradient of the same family: dw[cs,cl,kh,kw] = sum_{n,p,q} small[n,p,q,cs] *
+ * large[n,2p-1+kh,2q-1+kw,cl]; dw_dev in torch layout (Cs,Cl,4,4). */
+int siggan_op_conv4x4s2_wgrad(siggan_ctx *ctx, const float *small_dev, const float *large_dev,
+                              float *dw_dev, int32_t batch, int32_t h_small, int32_t c_small,
+                              int32_t c_large, void *stream);
+/* fused Adam over a flat arena (torch.optim.Adam single step, step = count AFTER increment) */
+int siggan_op_adam(siggan_ctx *ctx, float *p_dev, float *g_dev, float *m_dev, float *v_dev,
+                   int64_t n, int32_t step, const siggan_hyper *hp, void *stream);
+/* library RNG: n standard normals / n Bernoulli(keep) keep-masks */
+int siggan_op_randn(siggan_ctx *ctx, float *out_dev, int64_t n, void *stream);
+/* test hook: copy the first n floats of a library-owned workspace tensor (NHWC) into out_dev:
+ * "g_y"/"g_a"/"g_da" (layer 0..Lg), "d_a"/"d_dv" (block 1..Ld), "img", "dpre", "logits",
+ * "probs", "dlogit".  Used by tests that localise a parity failure. */
+int siggan_debug_tensor(siggan_ctx *ctx, const char *name, int32_t index, float *out_dev, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGGAN_H */

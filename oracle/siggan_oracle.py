@@ -95,11 +95,43 @@ def param_names(specs) -> List[str]:
 # --------------------------------------------------------------------------------------
 # forward passes
 # --------------------------------------------------------------------------------------
-def g_forward(sd: Dict[str, Tensor], z: Tensor, training: bool, size: int) -> Tensor:
+class _ActWithGivenSign(torch.autograd.Function):
+    """(Leaky)ReLU whose BACKWARD uses a supplied ``positive`` mask instead of its own x > 0.
+
+    Two correct fp32 implementations disagree on the sign of a pre-activation that is within
+    rounding (~1e-7 of the layer's scale) of zero; at batch 64 a step has ~1e7 activations, so
+    about one such coin-flip per step is expected, and it moves several gradient sums by far more
+    than 1e-3.  Parity tests therefore hand the OTHER implementation's sign decisions to the
+    oracle (and separately bound how many disagree and how close to zero those are)."""
+
+    @staticmethod
+    def forward(ctx, x, positive, slope):
+        ctx.save_for_backward(positive)
+        ctx.slope = slope
+        return torch.where(x > 0, x, x * slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        (positive,) = ctx.saved_tensors
+        return g * torch.where(positive, torch.ones_like(g), torch.full_like(g, ctx.slope)), None, None
+
+
+def _act(x: Tensor, slope: float, given: Optional[Tensor], record: Optional[list]):
+    if record is not None:
+        record.append(x.detach())
+    if given is None:
+        return F.leaky_relu(x, slope) if slope != 0.0 else F.relu(x)
+    return _ActWithGivenSign.apply(x, given.reshape(x.shape), slope)
+
+
+def g_forward(sd: Dict[str, Tensor], z: Tensor, training: bool, size: int,
+              signs: Optional[Sequence[Tensor]] = None, record: Optional[list] = None) -> Tensor:
     """Generator.forward (generator_vanilla_gan.py:189-209).  ``training`` selects the
     BatchNorm mode; in training mode running stats / num_batches_tracked in ``sd`` are
-    updated in place exactly as nn.BatchNorm does (momentum 0.1, unbiased running var)."""
+    updated in place exactly as nn.BatchNorm does (momentum 0.1, unbiased running var).
+    ``signs`` / ``record``: see _ActWithGivenSign (one entry per ReLU, NCHW bool)."""
     chain = G_CHAIN[size]
+    sg = (lambda i: None) if signs is None else (lambda i: signs[i])
 
     def bn(x, prefix):
         if training:
@@ -109,19 +141,20 @@ def g_forward(sd: Dict[str, Tensor], z: Tensor, training: bool, size: int) -> Te
                             training, BN_MOMENTUM, BN_EPS)
 
     x = F.linear(z, sd["fc.0.weight"], sd["fc.0.bias"])
-    x = F.relu(bn(x, "fc.1."))
+    x = _act(bn(x, "fc.1."), 0.0, sg(0), record)
     x = x.view(-1, chain[0], 4, 4)
     for i in range(len(chain) - 1):
         p = f"upsample_blocks.{i}.block."
         x = F.conv_transpose2d(x, sd[p + "0.weight"], None, stride=2, padding=1)
-        x = F.relu(bn(x, p + "1."))
+        x = _act(bn(x, p + "1."), 0.0, sg(i + 1), record)
     x = F.conv2d(x, sd["final_conv.0.weight"], sd["final_conv.0.bias"], stride=1, padding=1)
     return torch.tanh(x)
 
 
 def d_features(sd: Dict[str, Tensor], x: Tensor, size: int,
                masks: Optional[Sequence[Tensor]] = None,
-               dropout: float = 0.25, slope: float = 0.2) -> Tensor:
+               dropout: float = 0.25, slope: float = 0.2,
+               signs: Optional[Sequence[Tensor]] = None, record: Optional[list] = None) -> Tensor:
     """Discriminator.forward_features (discriminator_vanilla_gan.py:262-274).  ``masks`` is a
     list of (B, C_i) keep masks (1 keep / 0 drop), one per block, standing in for the hidden
     RNG of nn.Dropout2d (:74-75); None means eval mode (dropout off)."""
@@ -129,16 +162,16 @@ def d_features(sd: Dict[str, Tensor], x: Tensor, size: int,
     for i in range(n_blocks):
         p = f"conv_blocks.{i}.block.0."
         x = F.conv2d(x, sd[p + "weight"], sd[p + "bias"], stride=2, padding=1)
-        x = F.leaky_relu(x, slope)
+        x = _act(x, slope, None if signs is None else signs[i], record)
         if masks is not None and dropout > 0:
             noise = masks[i].to(x.dtype) / (1.0 - dropout)     # bernoulli(1-p).div_(1-p)
             x = x * noise[:, :, None, None]
     return x.flatten(1)
 
 
-def d_forward(sd, x, size, masks=None, dropout=0.25, slope=0.2) -> Tensor:
+def d_forward(sd, x, size, masks=None, dropout=0.25, slope=0.2, signs=None, record=None) -> Tensor:
     """Discriminator.forward (:241-260): probabilities (B,1)."""
-    f = d_features(sd, x, size, masks, dropout, slope)
+    f = d_features(sd, x, size, masks, dropout, slope, signs, record)
     return torch.sigmoid(F.linear(f, sd["classifier.0.weight"], sd["classifier.0.bias"]))
 
 
@@ -199,7 +232,7 @@ def _leafs(sd, names):
 
 
 def d_grads(g_sd, d_sd, real: Tensor, z: Tensor, masks_real, masks_fake, size: int,
-            label_smoothing: float = 0.9, dropout: float = 0.25):
+            label_smoothing: float = 0.9, dropout: float = 0.25, signs=None, record=None):
     """Forward/backward half of the D step (vanilla_gan_model.py:204-233 ==
     train_vanilla_gan_signatures.py:294-323): returns (metrics, grads, real_preds, fake_preds,
     fake_images).  G runs in eval mode under no_grad; only D parameters receive gradients."""
@@ -207,9 +240,11 @@ def d_grads(g_sd, d_sd, real: Tensor, z: Tensor, masks_real, masks_fake, size: i
     leaf = _leafs(d_sd, names)
     with torch.no_grad():
         fake = g_forward(g_sd, z, training=False, size=size)
-    real_preds = d_forward(leaf, real, size, masks_real, dropout)
+    nb = len(D_CHAIN[size])
+    s_real, s_fake = (None, None) if signs is None else (signs[:nb], signs[nb:])
+    real_preds = d_forward(leaf, real, size, masks_real, dropout, signs=s_real, record=record)
     loss_real = bce(real_preds, label_smoothing)
-    fake_preds = d_forward(leaf, fake, size, masks_fake, dropout)
+    fake_preds = d_forward(leaf, fake, size, masks_fake, dropout, signs=s_fake, record=record)
     loss_fake = bce(fake_preds, 0.0)
     loss = loss_real + loss_fake
     gl = torch.autograd.grad(loss, [leaf[k] for k in names])
@@ -225,18 +260,20 @@ def d_grads(g_sd, d_sd, real: Tensor, z: Tensor, masks_real, masks_fake, size: i
     return metrics, grads, real_preds.detach(), fake_preds.detach(), fake
 
 
-def g_grads(g_sd, d_sd, z: Tensor, size: int):
+def g_grads(g_sd, d_sd, z: Tensor, size: int, signs=None, record=None):
     """Forward/backward half of the G step (vanilla_gan_model.py:274-297 ==
     train_vanilla_gan_signatures.py:349-365): G in train mode (BN batch statistics, running
     stats updated in ``g_sd``), D in eval mode (dropout off), BCE against 1.0 (no smoothing)."""
     names = param_names(g_state_specs(z.shape[1], size))
     leaf = dict(g_sd)
     leaf.update(_leafs(g_sd, names))
-    fake = g_forward(leaf, z, training=True, size=size)
+    ng = len(G_CHAIN[size])
+    s_g, s_d = (None, None) if signs is None else (signs[:ng], signs[ng:])
+    fake = g_forward(leaf, z, training=True, size=size, signs=s_g, record=record)
     for k in g_sd:                      # running stats / counters were updated on the copies
         if k not in names:
             g_sd[k] = leaf[k]
-    fake_preds = d_forward(d_sd, fake, size, None)
+    fake_preds = d_forward(d_sd, fake, size, None, signs=s_d, record=record)
     loss = bce(fake_preds, 1.0)
     gl = torch.autograd.grad(loss, [leaf[k] for k in names])
     grads = {k: g.detach() for k, g in zip(names, gl)}
@@ -247,17 +284,17 @@ def g_grads(g_sd, d_sd, z: Tensor, size: int):
 
 def d_step(g_sd, d_sd, d_opt: AdamState, real, z, masks_real, masks_fake, size,
            lr=2e-4, beta1=0.5, beta2=0.999, label_smoothing=0.9, clip: Optional[float] = None,
-           dropout: float = 0.25):
+           dropout: float = 0.25, signs=None, record=None):
     metrics, grads, rp, fp, fake = d_grads(g_sd, d_sd, real, z, masks_real, masks_fake, size,
-                                           label_smoothing, dropout)
+                                           label_smoothing, dropout, signs, record)
     metrics["d_grad_norm"] = clip_grad_norm(list(grads.values()), clip) if clip is not None else None
     d_opt.apply(d_sd, grads, lr, beta1, beta2)
     return metrics, grads
 
 
 def g_step(g_sd, d_sd, g_opt: AdamState, z, size, lr=2e-4, beta1=0.5, beta2=0.999,
-           clip: Optional[float] = None):
-    metrics, grads, fp, fake = g_grads(g_sd, d_sd, z, size)
+           clip: Optional[float] = None, signs=None, record=None):
+    metrics, grads, fp, fake = g_grads(g_sd, d_sd, z, size, signs, record)
     metrics["g_grad_norm"] = clip_grad_norm(list(grads.values()), clip) if clip is not None else None
     g_opt.apply(g_sd, grads, lr, beta1, beta2)
     return metrics, grads

@@ -1,0 +1,55 @@
+// gconv.h -- argument blocks of the MFMA implicit-GEMM kernels (4x4 stride-2 pad-1 family).
+// All activations are NHWC fp32 inside the library; see DESIGN.md "data layout in HBM".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace siggan {
+
+enum Epilogue : int {
+    EPI_RAW = 0,          // store the accumulator
+    EPI_BIAS_LRELU_DROP,  // leaky(acc + bias[c]) * noise[n,c]         (Discriminator block forward)
+    EPI_AFFINE_RELU,      // relu(acc * scale[c] + shift[c])           (Generator block, BN eval folded)
+    EPI_LRELU_BWD,        // acc * leaky'(aref) * noise[n,c]           (Discriminator input-gradient)
+};
+
+// out[n, opix, co] = sum_{tap, ci} in[n, pix(tap), ci] * wp[cls][co][tap*Ci + ci]
+struct GConvArgs {
+    const float* in;      // [B][Hi][Wi][Ci]
+    const float* wp;      // packed weights [ncls][Co][ntaps*Ci]
+    float* out;           // [B][Ho][Wo][Co]
+    int B, Hi, Wi, Ci, Co;
+    int lgHr, lgWr;       // log2 of the per-image row grid (down: Ho,Wo; up: Hi,Wi)
+    int Ho, Wo;
+    int form;             // 0 = down (16 taps), 1 = up (4 parity classes x 4 taps)
+    int M;                // B * Hr * Wr rows (per class)
+    int epi;
+    const float* bias;    // [Co]
+    const float* noise;   // [B][Co] dropout multipliers (0 or 1/(1-p)); nullptr = none
+    const float* scale;   // [Co]
+    const float* shift;   // [Co]
+    const float* aref;    // [B][Ho][Wo][Co] stored activation (EPI_LRELU_BWD)
+    float slope;
+};
+
+// slab[z][i][tap*Cl + l] = sum_{pix in split z} S[pix][i] * L[n, 2p-1+kh, 2q-1+kw][l]
+struct WgradArgs {
+    const float* S;       // [B][Hs][Ws][Cs]   (small spatial)
+    const float* L;       // [B][2Hs][2Ws][Cl] (large spatial)
+    float* slab;          // [nsplit][Cs][16*Cl]
+    int B, Cs, Cl;
+    int lgHs, lgWs, lgCl;
+    int K;                // B*Hs*Ws pixels
+    int kchunk;           // pixels per split (multiple of 32)
+};
+
+void launch_gconv(const GConvArgs& a, hipStream_t st);
+// returns the number of K splits it used (slab must hold max_splits*Cs*16*Cl floats)
+int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st);
+// dw[(s*Cl + l)*16 + tap] (+)= sum_z slab[z][s][tap*Cl + l]
+void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int Cs, int Cl, hipStream_t st);
+// torch layout (O,I,4,4) -> down pack [O][tap*I + i];  torch (I,O,4,4) -> up pack [4][O][t*I + i]
+void launch_pack_down(const float* w, float* wp, int O, int I, hipStream_t st);
+void launch_pack_up(const float* w, float* wp, int I, int O, hipStream_t st);
+
+}  // namespace siggan

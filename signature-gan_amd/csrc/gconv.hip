@@ -1,0 +1,392 @@
+// gconv.hip -- fp32 MFMA implicit-GEMM kernels for the 4x4 / stride-2 / pad-1 convolution family
+// of the signature GAN (gfx950 only).
+//
+//   "down" form : Conv2d forward (discriminator_vanilla_gan.py:51-58) and the input-gradient of
+//                 ConvTranspose2d (generator_vanilla_gan.py:46-54)
+//   "up"   form : ConvTranspose2d forward and the input-gradient of Conv2d, as four sub-pixel
+//                 (output-parity) classes of 2x2 taps each -- no col2im scatter
+//   wgrad       : weight gradient of both, split over the pixel (K) axis into partial slabs
+//
+// GEMM view: C[m][n] = sum_k A[m][k] * Bw[n][k];  m = output pixel (down) / input pixel (up),
+// n = output channel, k = (tap, input channel).  One workgroup = 4 waves (256 threads); each wave
+// owns TM x TN tiles of 32x32 computed with v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).
+// LDS tiles are stored k-major ([k][row]) so a fragment read is one conflict-free ds_read_b32 per
+// lane (lane l reads row l&31 of k-row 2s + (l>>5)); the fp32 MFMA takes 64 cycles, so LDS and
+// VALU have a large budget and the kernels are MFMA-bound once the grid fills the chip.
+// Global->LDS staging is register-staged and software-pipelined one K-tile ahead (loads for tile
+// t+1 are issued before the MFMAs of tile t, written to the other LDS buffer after them).
+#include "gconv.h"
+
+namespace siggan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BK = 32;    // K-tile (floats)
+static constexpr int PAD = 4;    // LDS row padding (floats)
+
+// XCD-aware bijective remap (8 XCDs, blocks b and b+8 share an L2): consecutive logical tiles,
+// which share an A row-panel, land on one XCD.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int LDA = BM + PAD, LDB = BN + PAD;
+    __shared__ float smem[2 * BK * (LDA + LDB)];
+    float* const sA = smem;
+    float* const sB = smem + 2 * BK * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int tiles_n = a.Co / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
+    const int Hr = 1 << a.lgHr, Wr = 1 << a.lgWr;
+    const int ntaps = a.form == 0 ? 16 : 4;
+    const int Ktot = ntaps * a.Ci;
+    const int cpt = a.Ci / BK;                 // K-tiles per tap (power of two)
+    const int nk = ntaps * cpt;
+
+    // ---- per-thread staging coordinates -------------------------------------------------
+    const int kc = tid & 7, rloc = tid >> 3;   // 8 float4 chunks per 32-float k-row
+    int a_nb[PA], a_ih0[PA], a_iw0[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int m = m0 + rloc + 32 * p;
+        if (m < a.M) {
+            const int n = m >> (a.lgHr + a.lgWr);
+            const int rh = (m >> a.lgWr) & (Hr - 1), rw = m & (Wr - 1);
+            a_nb[p] = n * a.Hi * a.Wi;
+            if (a.form == 0) { a_ih0[p] = 2 * rh - 1; a_iw0[p] = 2 * rw - 1; }
+            else             { a_ih0[p] = rh + ph;    a_iw0[p] = rw + pw; }
+        } else {
+            a_nb[p] = 0; a_ih0[p] = -(1 << 20); a_iw0[p] = -(1 << 20);
+        }
+    }
+    const float* const wbase = a.wp + ((size_t)cls * a.Co + n0 + rloc) * Ktot + kc * 4;
+
+    float4 ra[PA], rb[PB];
+    auto load_tile = [&](int kt) {
+        const int tap = kt / cpt, ci0 = (kt - tap * cpt) * BK;
+        int dh, dw;
+        if (a.form == 0) { dh = tap >> 2; dw = tap & 3; } else { dh = -(tap >> 1); dw = -(tap & 1); }
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int ih = a_ih0[p] + dh, iw = a_iw0[p] + dw;
+            const bool ok = (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+            if (ok) {
+                const size_t off = ((size_t)(a_nb[p] + ih * a.Wi + iw)) * a.Ci + ci0 + kc * 4;
+                ra[p] = *reinterpret_cast<const float4*>(a.in + off);
+            } else {
+                ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            rb[p] = *reinterpret_cast<const float4*>(wbase + (size_t)(32 * p) * Ktot + kt * BK);
+    };
+    auto store_tile = [&](int buf) {
+        float* dA = sA + buf * BK * LDA + (kc * 4) * LDA + rloc;
+        float* dB = sB + buf * BK * LDB + (kc * 4) * LDB + rloc;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            dA[0 * LDA + 32 * p] = ra[p].x; dA[1 * LDA + 32 * p] = ra[p].y;
+            dA[2 * LDA + 32 * p] = ra[p].z; dA[3 * LDA + 32 * p] = ra[p].w;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            dB[0 * LDB + 32 * p] = rb[p].x; dB[1 * LDB + 32 * p] = rb[p].y;
+            dB[2 * LDB + 32 * p] = rb[p].z; dB[3 * LDB + 32 * p] = rb[p].w;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* pA = sA + buf * BK * LDA + lh * LDA + wm * (32 * TM) + li;
+        const float* pB = sB + buf * BK * LDB + lh * LDB + wn * (32 * TN) + li;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = pA[(2 * s) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = pB[(2 * s) * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= a.M) continue;
+            const int n = m >> (a.lgHr + a.lgWr);
+            size_t opix;
+            if (a.form == 0) {
+                opix = (size_t)m;
+            } else {
+                const int rh = (m >> a.lgWr) & (Hr - 1), rw = m & (Wr - 1);
+                opix = ((size_t)n * a.Ho + 2 * rh + ph) * a.Wo + 2 * rw + pw;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int co = n0 + wn * (32 * TN) + 32 * j + li;
+                float v = acc[i][j][r];
+                const size_t o = opix * a.Co + co;
+                if (a.epi == EPI_BIAS_LRELU_DROP) {
+                    v += a.bias[co];
+                    v = v > 0.f ? v : v * a.slope;
+                    if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
+                } else if (a.epi == EPI_AFFINE_RELU) {
+                    v = fmaxf(fmaf(v, a.scale[co], a.shift[co]), 0.f);
+                } else if (a.epi == EPI_LRELU_BWD) {
+                    const float ar = a.aref[o];
+                    v *= ar > 0.f ? 1.f : a.slope;
+                    if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
+                }
+                a.out[o] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(const GConvArgs& a, hipStream_t st) {
+    const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
+    dim3 grid(tiles, 1, a.form == 0 ? 1 : 4);
+    hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+}
+
+void launch_gconv(const GConvArgs& a, hipStream_t st) {
+    // Pick the largest tile that still yields >= ~256 workgroups (one per CU); Co is a
+    // multiple of 32 and a power of two for every layer of the model.
+    const int ncls = a.form == 0 ? 1 : 4;
+    auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * (a.Co / bn) * ncls; };
+    if (a.Co >= 64) {
+        if (a.Co >= 128 && blocks(128, 128) >= 256) return launch_cfg<128, 128, 2, 2>(a, st);
+        if (blocks(128, 64) >= 256) return launch_cfg<128, 64, 2, 2>(a, st);
+        return launch_cfg<64, 64, 2, 2>(a, st);
+    }
+    return launch_cfg<128, 32, 4, 1>(a, st);   // Co == 32
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient: C[i][j] = sum_pix S[pix][i] * Lg[pix][j],  j = tap*Cl + l
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int LDA = BM + PAD, LDB = BN + PAD;
+    constexpr int CA = BM / 4, RA = 256 / CA, PA = BK / RA;     // float4 chunks per k-row, rows per pass
+    constexpr int CB = BN / 4, RB = 256 / CB, PB = BK / RB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+    float* const sA = smem;
+    float* const sB = smem + 2 * BK * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int N = 16 << a.lgCl;
+    const int tiles_n = N / BN;
+    const int i0 = (blockIdx.x / tiles_n) * BM, j0 = (blockIdx.x % tiles_n) * BN;
+    const int kbeg = blockIdx.z * a.kchunk;
+    const int kend = min(a.K, kbeg + a.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int Hs = 1 << a.lgHs, Ws = 1 << a.lgWs, Hl = 2 * Hs, Wl = 2 * Ws, Cl = 1 << a.lgCl;
+
+    const int ca = tid % CA, ka = tid / CA;
+    const int cb = tid % CB, kb = tid / CB;
+    const int jj = j0 + cb * 4, tap = jj >> a.lgCl, lch = jj & (Cl - 1);
+    const int kh = tap >> 2, kw = tap & 3;
+
+    float4 ra[PA], rb[PB];
+    auto load_tile = [&](int kt) {
+        const int kbase = kbeg + kt * BK;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int pix = kbase + ka + RA * p;
+            ra[p] = pix < kend ? *reinterpret_cast<const float4*>(a.S + (size_t)pix * a.Cs + i0 + ca * 4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int pix = kbase + kb + RB * p;
+            bool ok = pix < kend;
+            const int n = pix >> (a.lgHs + a.lgWs);
+            const int ih = 2 * ((pix >> a.lgWs) & (Hs - 1)) - 1 + kh, iw = 2 * (pix & (Ws - 1)) - 1 + kw;
+            ok = ok && (unsigned)ih < (unsigned)Hl && (unsigned)iw < (unsigned)Wl;
+            rb[p] = ok ? *reinterpret_cast<const float4*>(a.L + (((size_t)n * Hl + ih) * Wl + iw) * Cl + lch)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            *reinterpret_cast<float4*>(sA + buf * BK * LDA + (ka + RA * p) * LDA + ca * 4) = ra[p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<float4*>(sB + buf * BK * LDB + (kb + RB * p) * LDB + cb * 4) = rb[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* pA = sA + buf * BK * LDA + lh * LDA + wm * (32 * TM) + li;
+        const float* pB = sB + buf * BK * LDB + lh * LDB + wn * (32 * TN) + li;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = pA[(2 * s) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = pB[(2 * s) * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* const out = a.slab + (size_t)blockIdx.z * a.Cs * N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                out[(size_t)row * N + j0 + wn * (32 * TN) + 32 * j + li] = acc[i][j][r];
+        }
+}
+
+int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
+    const int N = 16 << a.lgCl;
+    const int bm = a.Cs >= 128 ? 128 : a.Cs;                 // Cs in {32,64,128,256,512}
+    const int tiles = (a.Cs / bm) * (N / 128);
+    // enough K splits to put ~2 workgroups on every CU, at least 2 K-tiles per split
+    int ktiles = (a.K + BK - 1) / BK;
+    int want = (512 + tiles - 1) / tiles;
+    int nsplit = want < 1 ? 1 : want;
+    if (nsplit > ktiles / 2) nsplit = ktiles / 2 > 0 ? ktiles / 2 : 1;
+    if (nsplit > max_splits) nsplit = max_splits;
+    int per = (ktiles + nsplit - 1) / nsplit;
+    a.kchunk = per * BK;
+    nsplit = (ktiles + per - 1) / per;
+    dim3 grid(tiles, 1, nsplit);
+    if (bm == 128) hipLaunchKernelGGL((k_wgrad<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
+    else if (bm == 64) hipLaunchKernelGGL((k_wgrad<64, 128, 2, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, a);
+    return nsplit;
+}
+
+__global__ void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
+                               int Cs, int lgCl) {
+    const int N = 16 << lgCl, Cl = 1 << lgCl;
+    const size_t total = (size_t)Cs * N;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % N), s = (int)(idx / N);
+        float acc = 0.f;
+        for (int z = 0; z < nsplit; ++z) acc += slab[(size_t)z * total + idx];
+        const int tap = j >> lgCl, l = j & (Cl - 1);
+        dw[((size_t)s * Cl + l) * 16 + tap] = acc;
+    }
+}
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int Cs, int Cl, hipStream_t st) {
+    const size_t total = (size_t)Cs * 16 * Cl;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, slab, dw, nsplit, Cs, ilog2(Cl));
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing (torch layouts -> GEMM-friendly k-contiguous rows)
+// ------------------------------------------------------------------------------------------
+__global__ void k_pack_down(const float* __restrict__ w, float* __restrict__ wp, int O, int I) {
+    // w[o][i][kh][kw] -> wp[o][(kh*4+kw)*I + i]
+    const size_t total = (size_t)O * I * 16;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % I);
+        const int tap = (int)((idx / I) % 16);
+        const int o = (int)(idx / ((size_t)I * 16));
+        wp[idx] = w[((size_t)o * I + i) * 16 + tap];
+    }
+}
+
+__global__ void k_pack_up(const float* __restrict__ w, float* __restrict__ wp, int I, int O) {
+    // w[i][o][kh][kw] -> wp[cls=(ph,pw)][o][(th*2+tw)*I + i],  kh = 1-ph+2th, kw = 1-pw+2tw
+    const size_t total = (size_t)O * I * 16;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % I);
+        const int t = (int)((idx / I) % 4);
+        const int o = (int)((idx / ((size_t)I * 4)) % O);
+        const int cls = (int)(idx / ((size_t)I * 4 * O));
+        const int ph = cls >> 1, pw = cls & 1, th = t >> 1, tw = t & 1;
+        const int kh = 1 - ph + 2 * th, kw = 1 - pw + 2 * tw;
+        wp[idx] = w[((size_t)i * O + o) * 16 + kh * 4 + kw];
+    }
+}
+
+void launch_pack_down(const float* w, float* wp, int O, int I, hipStream_t st) {
+    const size_t total = (size_t)O * I * 16;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_pack_down, dim3(blocks), dim3(256), 0, st, w, wp, O, I);
+}
+void launch_pack_up(const float* w, float* wp, int I, int O, hipStream_t st) {
+    const size_t total = (size_t)O * I * 16;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_pack_up, dim3(blocks), dim3(256), 0, st, w, wp, I, O);
+}
+
+}  // namespace siggan

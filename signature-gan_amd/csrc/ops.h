@@ -1,0 +1,89 @@
+// ops.h -- the bandwidth-bound kernels around the MFMA GEMMs (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace siggan {
+
+// device-resident per-call state: nothing a captured launch needs lives in kernel arguments
+struct DevState {
+    unsigned long long seed;
+    unsigned long long rng_ctr;      // bumped once per step phase
+    // scalars of the pending Adam apply (written by k_adam_prepare)
+    float step_size;                 // lr / (1 - beta1^t)
+    float bc2_sqrt;                  // sqrt(1 - beta2^t)
+    float grad_mul;                  // grad_scale * clip coefficient
+    float grad_norm;                 // pre-clip global L2 norm (after grad_scale)
+    float sumsq;                     // scratch of the norm reduction
+    float pad[3];
+};
+
+// ---- RNG (Philox4x32-10, counter = (index, stream, call counter)) --------------------------
+void launch_randn(float* out, int64_t n, const DevState* st, uint32_t stream_id, hipStream_t s);
+// out = u < keep ? 1/keep : 0
+void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uint32_t stream_id, hipStream_t s);
+// out = mask * (1/keep)
+void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, hipStream_t s);
+void launch_tick(DevState* st, hipStream_t s);
+
+// ---- Generator pieces ---------------------------------------------------------------------
+// y[n][f'] = z[n,:] . W[f,:] + b[f],  f' = hw*C0 + c  <->  f = c*16 + hw   (NHWC feature order)
+void launch_fc_fwd(const float* z, const float* W, const float* b, float* y, int B, int K, int C0, hipStream_t s);
+// dW[f][k] = sum_n dy[n][f'] z[n][k];  db[f] = sum_n dy[n][f']
+void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s);
+
+// BatchNorm.  perm_c0 > 0: channel c' of the data maps to torch index (c' % perm_c0)*16 + c'/perm_c0
+// (BatchNorm1d behind the fc); 0: identity.  Per-layer scratch `bn` holds 6*C floats:
+// [scale | shift | mean | rstd | c1 | c2].
+void launch_bn_eval_affine(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                           float* bn, int C, int perm_c0, float eps, hipStream_t s);
+// training statistics over R rows + running-stat update (momentum, unbiased var) + batches++
+void launch_bn_train_stats(const float* y, int64_t R, int C, const float* gamma, const float* beta,
+                           float* rmean, float* rvar, int64_t* batches, float* bn, float* partial,
+                           int perm_c0, float momentum, float eps, hipStream_t s);
+// a = relu(y*scale + shift)
+void launch_bn_relu(const float* y, float* a, int64_t R, int C, const float* bn, hipStream_t s);
+// backward through relu(BN(y)): da (in) -> dy (in place); dgamma/dbeta (torch order) written
+void launch_bn_bwd(float* da, const float* y, const float* a, int64_t R, int C, float* bn, float* partial,
+                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s);
+
+// final 3x3 conv (C->1) + tanh, and its backward pieces.  act: [B][S][S][C] NHWC, img [B][S][S]
+void launch_final_fwd(const float* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s);
+void launch_final_dgrad(const float* dpre, const float* W, float* dact, int B, int S, int C, hipStream_t s);
+void launch_final_wgrad(const float* dpre, const float* act, float* dW, float* db, float* partial, int B, int S,
+                        int C, hipStream_t s);
+
+// ---- Discriminator pieces -----------------------------------------------------------------
+// first block (Cin = 1): x = two segments (x0: n < n0, x1: the rest), out [B][S/2][S/2][C]
+void launch_conv1_fwd(const float* x0, int n0, const float* x1, const float* W, const float* b,
+                      const float* noise, float slope, float* out, int B, int S, int C, hipStream_t s);
+void launch_conv1_wgrad(const float* dv, const float* x0, int n0, const float* x1, float* dW, float* db,
+                        float* partial, int B, int S, int C, hipStream_t s);
+// d(image) = conv1 input-gradient, times tanh' = 1 - img^2  ->  dpre
+void launch_conv1_dgrad_tanh(const float* dv, const float* W, const float* img, float* dpre, int B, int S,
+                             int C, hipStream_t s);
+// classifier: logits[n] = act[n,:] . wcp + bc   (act NHWC-flattened, wcp the permuted weight)
+void launch_cls_pack(const float* Wc, float* wcp, int C, hipStream_t s);
+void launch_cls_fwd(const float* act, const float* wcp, const float* bc, float* logits, int B, int F, hipStream_t s);
+void launch_cls_features(const float* act, float* feat, int B, int C, hipStream_t s);
+// sigmoid + BCE (mean per segment) + d(logit); seg0 = first n0 rows with target y0, rest target y1
+void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* probs, float* dlogit,
+                float* metrics, int is_g_step, hipStream_t s);
+// dv[n][hw][c] = dlogit[n] * wcp[hw*C+c] * leaky'(act) * noise[n][c]
+void launch_cls_bwd(const float* dlogit, const float* wcp, const float* act, const float* noise, float slope,
+                    float* dv, int B, int C, hipStream_t s);
+// dWc (torch order c*16+hw) and dbc
+void launch_cls_wgrad(const float* dlogit, const float* act, float* dWc, float* dbc, int B, int C, hipStream_t s);
+// out[c] = sum_r x[r][c]
+void launch_colsum(const float* x, int64_t R, int C, float* out, float* partial, hipStream_t s);
+
+// ---- optimiser ------------------------------------------------------------------------------
+// reads steps[0], writes steps[i] += 1 for every tensor, derives the Adam scalars; with
+// clip_max_norm > 0 also needs the gradient norm (launch_grad_sumsq first)
+void launch_grad_sumsq(const float* g, int64_t n, DevState* st, float* partial, hipStream_t s);
+void launch_adam_prepare(DevState* st, float* steps, int ntensors, double lr, double beta1, double beta2,
+                         float grad_scale, float clip_max_norm, float* metric_norm, hipStream_t s);
+void launch_adam(float* p, float* g, float* m, float* v, int64_t n, const DevState* st, double beta1,
+                 double beta2, double eps, int write_back_grad, hipStream_t s);
+
+}  // namespace siggan

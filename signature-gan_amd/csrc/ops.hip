@@ -1,0 +1,767 @@
+// ops.hip -- bandwidth-bound kernels of the signature-GAN step (gfx950): RNG, the C=1 end layers,
+// BatchNorm statistics / apply / backward, classifier + BCE, bias reductions, clip + Adam.
+// Every activation is NHWC fp32; consecutive lanes walk the channel axis (coalesced 128-256 B
+// segments) and per-channel reductions are two-stage (per-chunk partials, then a finalize
+// kernel that adds the partials in chunk order), so results are bitwise reproducible.
+#include "ops.h"
+
+namespace siggan {
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// =========================================================================================
+// RNG: Philox4x32-10
+// =========================================================================================
+__device__ __forceinline__ uint4 philox(uint4 c, uint2 k) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += W0; k.y += W1;
+    }
+    return c;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__device__ __forceinline__ uint4 draw(const DevState* st, uint64_t idx, uint32_t stream_id) {
+    const unsigned long long ctr = st->rng_ctr, seed = st->seed;
+    return philox(make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), stream_id, (uint32_t)ctr),
+                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(ctr >> 32)));
+}
+
+__global__ void k_randn(float* __restrict__ out, int64_t n, const DevState* __restrict__ st, uint32_t sid) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * 4 >= n) return;
+    const uint4 r = draw(st, (uint64_t)t, sid);
+    const float r0 = sqrtf(-2.0f * logf(u01(r.x))), r1 = sqrtf(-2.0f * logf(u01(r.z)));
+    const float a0 = 6.283185307179586f * u01(r.y), a1 = 6.283185307179586f * u01(r.w);
+    const float v[4] = {r0 * cosf(a0), r0 * sinf(a0), r1 * cosf(a1), r1 * sinf(a1)};
+    for (int j = 0; j < 4 && t * 4 + j < n; ++j) out[t * 4 + j] = v[j];
+}
+__global__ void k_dropnoise(float* __restrict__ out, int64_t n, float keep, float inv, const DevState* __restrict__ st,
+                            uint32_t sid) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * 4 >= n) return;
+    const uint4 r = draw(st, (uint64_t)t, sid);
+    const uint32_t x[4] = {r.x, r.y, r.z, r.w};
+    for (int j = 0; j < 4 && t * 4 + j < n; ++j) out[t * 4 + j] = u01(x[j]) < keep ? inv : 0.f;
+}
+__global__ void k_mask_to_noise(const float* __restrict__ m, float* __restrict__ out, int64_t n, float inv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = m[i] * inv;
+}
+__global__ void k_tick(DevState* st) { st->rng_ctr += 1; }
+
+void launch_randn(float* out, int64_t n, const DevState* st, uint32_t sid, hipStream_t s) {
+    hipLaunchKernelGGL(k_randn, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, out, n, st, sid);
+}
+void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uint32_t sid, hipStream_t s) {
+    hipLaunchKernelGGL(k_dropnoise, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, out, n, keep, 1.0f / keep, st, sid);
+}
+void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask_to_noise, dim3(cdiv(n, 256)), dim3(256), 0, s, mask, out, n, 1.0f / keep);
+}
+void launch_tick(DevState* st, hipStream_t s) { hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, s, st); }
+
+// =========================================================================================
+// generic two-stage column reduction: grid (C/64, chunks), block = 64 columns x 4 row lanes
+// =========================================================================================
+struct ColPlan { int nch; int rows; };
+static ColPlan col_plan(int64_t R, int C) {
+    const int cb = cdiv(C, 64);
+    int nch = 1024 / cb;
+    if (nch < 1) nch = 1;
+    const int64_t max_ch = (R + 15) / 16;
+    if (nch > max_ch) nch = (int)max_ch;
+    if (nch < 1) nch = 1;
+    int rows = (int)((R + nch - 1) / nch);
+    rows = (rows + 3) & ~3;
+    nch = (int)((R + rows - 1) / rows);
+    return {nch, rows};
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_colreduce(F f, int64_t R, int C, int rows, float* __restrict__ p0,
+                                                   float* __restrict__ p1) {
+    __shared__ float sh[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int64_t r0 = (int64_t)blockIdx.y * rows;
+    const int64_t r1 = r0 + rows < R ? r0 + rows : R;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + rl; r < r1; r += 4) f(r, c, s0, s1);
+    sh[0][rl][cl] = s0; sh[1][rl][cl] = s1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        p0[(size_t)blockIdx.y * C + c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+        p1[(size_t)blockIdx.y * C + c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+    }
+}
+
+struct FSum {
+    const float* x; int C;
+    __device__ void operator()(int64_t r, int c, float& s0, float& s1) const { s0 += x[r * C + c]; }
+};
+struct FStats {   // shifted sums around the first row: robust single-pass variance
+    const float* y; int C;
+    __device__ void operator()(int64_t r, int c, float& s0, float& s1) const {
+        const float v = y[r * C + c] - y[c];
+        s0 += v; s1 += v * v;
+    }
+};
+struct FBnBwd {
+    const float* da; const float* y; const float* a; const float* bn; int C;
+    __device__ void operator()(int64_t r, int c, float& s0, float& s1) const {
+        const size_t i = (size_t)r * C + c;
+        const float d = a[i] > 0.f ? da[i] : 0.f;
+        const float xh = (y[i] - bn[2 * C + c]) * bn[3 * C + c];
+        s0 += d; s1 += d * xh;
+    }
+};
+
+__device__ __forceinline__ int perm16(int c, int perm_c0) { return perm_c0 > 0 ? (c % perm_c0) * 16 + c / perm_c0 : c; }
+
+__global__ void k_colsum_fin(const float* __restrict__ p0, int nch, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nch; ++k) s += p0[(size_t)k * C + c];
+    out[c] = s;
+}
+void launch_colsum(const float* x, int64_t R, int C, float* out, float* partial, hipStream_t s) {
+    const ColPlan pl = col_plan(R, C);
+    float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
+    hipLaunchKernelGGL((k_colreduce<FSum>), dim3(cdiv(C, 64), pl.nch), dim3(256), 0, s, FSum{x, C}, R, C, pl.rows, p0, p1);
+    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(C, 256)), dim3(256), 0, s, p0, pl.nch, C, out);
+}
+
+// =========================================================================================
+// BatchNorm
+// =========================================================================================
+__global__ void k_bn_eval_affine(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                 float* __restrict__ bn, int C, int perm_c0, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int t = perm16(c, perm_c0);
+    const float rstd = 1.0f / sqrtf(rvar[t] + eps);
+    const float sc = gamma[t] * rstd;
+    bn[c] = sc; bn[C + c] = beta[t] - rmean[t] * sc; bn[2 * C + c] = rmean[t]; bn[3 * C + c] = rstd;
+}
+void launch_bn_eval_affine(const float* gamma, const float* beta, const float* rmean, const float* rvar, float* bn,
+                           int C, int perm_c0, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(k_bn_eval_affine, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, rmean, rvar, bn, C, perm_c0, eps);
+}
+
+__global__ void k_bn_train_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
+                               const float* __restrict__ y, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                               int64_t* __restrict__ batches, float* __restrict__ bn, int perm_c0, float momentum,
+                               float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && batches) batches[0] += 1;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < nch; ++k) { s += p0[(size_t)k * C + c]; q += p1[(size_t)k * C + c]; }
+    const float invR = 1.0f / (float)R;
+    const float d = s * invR;
+    const float mean = y[c] + d;
+    float var = q * invR - d * d;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const int t = perm16(c, perm_c0);
+    const float sc = gamma[t] * rstd;
+    bn[c] = sc; bn[C + c] = beta[t] - mean * sc; bn[2 * C + c] = mean; bn[3 * C + c] = rstd;
+    const float unb = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+    rmean[t] = momentum * mean + (1.0f - momentum) * rmean[t];
+    rvar[t] = momentum * unb + (1.0f - momentum) * rvar[t];
+}
+void launch_bn_train_stats(const float* y, int64_t R, int C, const float* gamma, const float* beta, float* rmean,
+                           float* rvar, int64_t* batches, float* bn, float* partial, int perm_c0, float momentum,
+                           float eps, hipStream_t s) {
+    const ColPlan pl = col_plan(R, C);
+    float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
+    hipLaunchKernelGGL((k_colreduce<FStats>), dim3(cdiv(C, 64), pl.nch), dim3(256), 0, s, FStats{y, C}, R, C, pl.rows, p0, p1);
+    hipLaunchKernelGGL(k_bn_train_fin, dim3(cdiv(C, 256)), dim3(256), 0, s, p0, p1, pl.nch, R, C, y, gamma, beta, rmean,
+                       rvar, batches, bn, perm_c0, momentum, eps);
+}
+
+__global__ void k_bn_relu(const float4* __restrict__ y, float4* __restrict__ a, int64_t n4, int C4,
+                          const float4* __restrict__ bn) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)(i % C4);
+    const float4 v = y[i], sc = bn[c], sh = bn[C4 + c];
+    a[i] = make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f),
+                       fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+}
+void launch_bn_relu(const float* y, float* a, int64_t R, int C, const float* bn, hipStream_t s) {
+    const int64_t n4 = R * C / 4;
+    hipLaunchKernelGGL(k_bn_relu, dim3(cdiv(n4, 256)), dim3(256), 0, s, (const float4*)y, (float4*)a, n4, C / 4,
+                       (const float4*)bn);
+}
+
+__global__ void k_bn_bwd_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
+                             float* __restrict__ bn, float* __restrict__ dgamma, float* __restrict__ dbeta, int perm_c0) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < nch; ++k) { s += p0[(size_t)k * C + c]; q += p1[(size_t)k * C + c]; }
+    const int t = perm16(c, perm_c0);
+    dbeta[t] = s; dgamma[t] = q;
+    const float invR = 1.0f / (float)R;
+    bn[4 * C + c] = s * invR; bn[5 * C + c] = q * invR;
+}
+__global__ void k_bn_bwd_apply(float4* __restrict__ da, const float4* __restrict__ y, const float4* __restrict__ a,
+                               int64_t n4, int C4, const float4* __restrict__ bn) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)(i % C4);
+    const float4 g = da[i], yy = y[i], aa = a[i];
+    const float4 sc = bn[c], mu = bn[2 * C4 + c], rs = bn[3 * C4 + c], c1 = bn[4 * C4 + c], c2 = bn[5 * C4 + c];
+    float4 o;
+    o.x = sc.x * ((aa.x > 0.f ? g.x : 0.f) - c1.x - (yy.x - mu.x) * rs.x * c2.x);
+    o.y = sc.y * ((aa.y > 0.f ? g.y : 0.f) - c1.y - (yy.y - mu.y) * rs.y * c2.y);
+    o.z = sc.z * ((aa.z > 0.f ? g.z : 0.f) - c1.z - (yy.z - mu.z) * rs.z * c2.z);
+    o.w = sc.w * ((aa.w > 0.f ? g.w : 0.f) - c1.w - (yy.w - mu.w) * rs.w * c2.w);
+    da[i] = o;
+}
+void launch_bn_bwd(float* da, const float* y, const float* a, int64_t R, int C, float* bn, float* partial,
+                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s) {
+    const ColPlan pl = col_plan(R, C);
+    float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
+    hipLaunchKernelGGL((k_colreduce<FBnBwd>), dim3(cdiv(C, 64), pl.nch), dim3(256), 0, s, FBnBwd{da, y, a, bn, C}, R, C,
+                       pl.rows, p0, p1);
+    hipLaunchKernelGGL(k_bn_bwd_fin, dim3(cdiv(C, 256)), dim3(256), 0, s, p0, p1, pl.nch, R, C, bn, dgamma, dbeta, perm_c0);
+    const int64_t n4 = R * C / 4;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, s, (float4*)da, (const float4*)y,
+                       (const float4*)a, n4, C / 4, (const float4*)bn);
+}
+
+// =========================================================================================
+// Generator fc (latent x weight) -- K = latent_dim is tiny; one thread per output
+// =========================================================================================
+__global__ void k_fc_fwd(const float* __restrict__ z, const float* __restrict__ W, const float* __restrict__ b,
+                         float* __restrict__ y, int B, int K, int C0) {
+    const int F = C0 * 16;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * F) return;
+    const int fp = (int)(idx % F), n = (int)(idx / F);
+    const int f = (fp % C0) * 16 + fp / C0;
+    const float* zr = z + (size_t)n * K; const float* wr = W + (size_t)f * K;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(zr[k], wr[k], acc);
+    y[idx] = acc + b[f];
+}
+void launch_fc_fwd(const float* z, const float* W, const float* b, float* y, int B, int K, int C0, hipStream_t s) {
+    hipLaunchKernelGGL(k_fc_fwd, dim3(cdiv((int64_t)B * C0 * 16, 256)), dim3(256), 0, s, z, W, b, y, B, K, C0);
+}
+__global__ void k_fc_wgrad(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dW,
+                           float* __restrict__ db, int B, int K, int C0) {
+    const int F = C0 * 16;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)(K + 1) * F) return;
+    const int fp = (int)(idx % F), k = (int)(idx / F);
+    const int f = (fp % C0) * 16 + fp / C0;
+    float acc = 0.f;
+    if (k < K) {
+        for (int n = 0; n < B; ++n) acc = fmaf(dy[(size_t)n * F + fp], z[(size_t)n * K + k], acc);
+        dW[(size_t)f * K + k] = acc;
+    } else {
+        for (int n = 0; n < B; ++n) acc += dy[(size_t)n * F + fp];
+        db[f] = acc;
+    }
+}
+void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s) {
+    hipLaunchKernelGGL(k_fc_wgrad, dim3(cdiv((int64_t)(K + 1) * C0 * 16, 256)), dim3(256), 0, s, dy, z, dW, db, B, K, C0);
+}
+
+// =========================================================================================
+// Generator final 3x3 conv (C -> 1) + tanh
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ act, const float* __restrict__ W,
+                                                   const float* __restrict__ b, float* __restrict__ img, int B, int S,
+                                                   int C) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];   // [9][C]
+    for (int i = threadIdx.x; i < 9 * C; i += 256) sW[i] = W[(i % C) * 9 + i / C];
+    __syncthreads();
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (int64_t)B * S * S) return;
+    const int w = (int)(pix % S), h = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
+    float acc = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hh = h + kh - 1;
+        if ((unsigned)hh >= (unsigned)S) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ww = w + kw - 1;
+            if ((unsigned)ww >= (unsigned)S) continue;
+            const float4* ap = (const float4*)(act + (((size_t)n * S + hh) * S + ww) * C);
+            const float4* wp = (const float4*)(sW + (kh * 3 + kw) * C);
+            for (int c = 0; c < C / 4; ++c) {
+                const float4 x = ap[c], ww4 = wp[c];
+                acc = fmaf(x.x, ww4.x, acc); acc = fmaf(x.y, ww4.y, acc);
+                acc = fmaf(x.z, ww4.z, acc); acc = fmaf(x.w, ww4.w, acc);
+            }
+        }
+    }
+    img[pix] = tanhf(acc + b[0]);
+}
+void launch_final_fwd(const float* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s) {
+    hipLaunchKernelGGL(k_final_fwd, dim3(cdiv((int64_t)B * S * S, 256)), dim3(256), 9 * C * sizeof(float), s, act, W, b,
+                       img, B, S, C);
+}
+
+__global__ __launch_bounds__(256) void k_final_dgrad(const float* __restrict__ dpre, const float* __restrict__ W,
+                                                     float* __restrict__ dact, int B, int S, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];   // [9][C]
+    for (int i = threadIdx.x; i < 9 * C; i += 256) sW[i] = W[(i % C) * 9 + i / C];
+    __syncthreads();
+    const int C4 = C / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * S * S * C4) return;
+    const int c4 = (int)(idx % C4);
+    const int64_t pix = idx / C4;
+    const int w = (int)(pix % S), h = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hh = h + 1 - kh;
+        if ((unsigned)hh >= (unsigned)S) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ww = w + 1 - kw;
+            if ((unsigned)ww >= (unsigned)S) continue;
+            const float d = dpre[((size_t)n * S + hh) * S + ww];
+            const float4 wv = *(const float4*)(sW + (kh * 3 + kw) * C + c4 * 4);
+            acc.x = fmaf(d, wv.x, acc.x); acc.y = fmaf(d, wv.y, acc.y);
+            acc.z = fmaf(d, wv.z, acc.z); acc.w = fmaf(d, wv.w, acc.w);
+        }
+    }
+    ((float4*)dact)[idx] = acc;
+}
+void launch_final_dgrad(const float* dpre, const float* W, float* dact, int B, int S, int C, hipStream_t s) {
+    hipLaunchKernelGGL(k_final_dgrad, dim3(cdiv((int64_t)B * S * S * (C / 4), 256)), dim3(256), 9 * C * sizeof(float), s,
+                       dpre, W, dact, B, S, C);
+}
+
+// block = C channel lanes x (256/C) pixel lanes; partial[chunk][C*9 + 1]
+__global__ __launch_bounds__(256) void k_final_wgrad(const float* __restrict__ dpre, const float* __restrict__ act,
+                                                     float* __restrict__ partial, int B, int S, int C, int ppb) {
+    __shared__ float sh[256 * 10];
+    const int ci = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
+    const int64_t total = (int64_t)B * S * S;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p1 = p0 + ppb < total ? p0 + ppb : total;
+    float acc[9], sdb = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int64_t pix = p0 + pl; pix < p1; pix += npl) {
+        const int w = (int)(pix % S), h = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
+        const float av = act[(size_t)pix * C + ci];
+        if (ci == 0) sdb += dpre[pix];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h - kh + 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ww = w - kw + 1;
+                if ((unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S)
+                    acc[kh * 3 + kw] = fmaf(av, dpre[((size_t)n * S + hh) * S + ww], acc[kh * 3 + kw]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sh[threadIdx.x * 10 + t] = acc[t];
+    sh[threadIdx.x * 10 + 9] = sdb;
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * (C * 9 + 1);
+    for (int o = threadIdx.x; o < C * 9 + 1; o += 256) {
+        float s = 0.f;
+        if (o < C * 9) {
+            const int c = o / 9, t = o % 9;
+            for (int k = 0; k < npl; ++k) s += sh[(k * C + c) * 10 + t];
+        } else {
+            for (int k = 0; k < npl; ++k) s += sh[(k * C) * 10 + 9];
+        }
+        out[o] = s;
+    }
+}
+__global__ void k_rows_sum(const float* __restrict__ partial, int nch, int width, float* __restrict__ o0, int n0,
+                           float* __restrict__ o1) {
+    // out[j] = sum_k partial[k][j];  j < n0 -> o0[j], else o1[j - n0]
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= width) return;
+    float s = 0.f;
+    for (int k = 0; k < nch; ++k) s += partial[(size_t)k * width + j];
+    if (j < n0) o0[j] = s; else o1[j - n0] = s;
+}
+void launch_final_wgrad(const float* dpre, const float* act, float* dW, float* db, float* partial, int B, int S, int C,
+                        hipStream_t s) {
+    const int64_t total = (int64_t)B * S * S;
+    int nch = 512;
+    int ppb = cdiv(total, nch);
+    ppb = ((ppb + 7) / 8) * 8;
+    nch = cdiv(total, ppb);
+    hipLaunchKernelGGL(k_final_wgrad, dim3(nch), dim3(256), 0, s, dpre, act, partial, B, S, C, ppb);
+    hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 256)), dim3(256), 0, s, partial, nch, C * 9 + 1, dW, C * 9, db);
+}
+
+// =========================================================================================
+// Discriminator first block (Cin = 1)
+// =========================================================================================
+__device__ __forceinline__ const float* seg_ptr(const float* x0, int n0, const float* x1, int n, int S) {
+    return n < n0 ? x0 + (size_t)n * S * S : x1 + (size_t)(n - n0) * S * S;
+}
+
+__global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x0, int n0, const float* __restrict__ x1,
+                                                   const float* __restrict__ W, const float* __restrict__ b,
+                                                   const float* __restrict__ noise, float slope,
+                                                   float* __restrict__ out, int B, int S, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];   // [16][C] then bias [C]
+    for (int i = threadIdx.x; i < 16 * C; i += 256) sW[i] = W[(i % C) * 16 + i / C];
+    for (int i = threadIdx.x; i < C; i += 256) sW[16 * C + i] = b[i];
+    __syncthreads();
+    const int Q = C / 4, ppb = 256 / Q, Ho = S / 2;
+    const int q = threadIdx.x % Q, pl = threadIdx.x / Q;
+    const int64_t pix = (int64_t)blockIdx.x * ppb + pl;
+    if (pix >= (int64_t)B * Ho * Ho) return;
+    const int ow = (int)(pix % Ho), oh = (int)((pix / Ho) % Ho), n = (int)(pix / ((int64_t)Ho * Ho));
+    const float* xp = seg_ptr(x0, n0, x1, n, S);
+    float4 acc = *(const float4*)(sW + 16 * C + q * 4);
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+        const int ih = 2 * oh - 1 + kh;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            const int iw = 2 * ow - 1 + kw;
+            const float xv = ((unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) ? xp[ih * S + iw] : 0.f;
+            const float4 wv = *(const float4*)(sW + (kh * 4 + kw) * C + q * 4);
+            acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
+            acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+        }
+    }
+    acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
+    acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
+    if (noise) {
+        const float4 nz = *(const float4*)(noise + (size_t)n * C + q * 4);
+        acc.x *= nz.x; acc.y *= nz.y; acc.z *= nz.z; acc.w *= nz.w;
+    }
+    *(float4*)(out + (size_t)pix * C + q * 4) = acc;
+}
+void launch_conv1_fwd(const float* x0, int n0, const float* x1, const float* W, const float* b, const float* noise,
+                      float slope, float* out, int B, int S, int C, hipStream_t s) {
+    const int ppb = 256 / (C / 4);
+    hipLaunchKernelGGL(k_conv1_fwd, dim3(cdiv((int64_t)B * (S / 2) * (S / 2), ppb)), dim3(256), 17 * C * sizeof(float), s,
+                       x0, n0, x1, W, b, noise, slope, out, B, S, C);
+}
+
+// block = C channel lanes x (256/C) pixel lanes; partial[chunk][C*17]  (16 taps + bias)
+__global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ dv, const float* __restrict__ x0, int n0,
+                                                     const float* __restrict__ x1, float* __restrict__ partial, int B,
+                                                     int S, int C, int ppb) {
+    extern __shared__ float sh[];   // [256][17]
+    const int co = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C, Ho = S / 2;
+    const int64_t total = (int64_t)B * Ho * Ho;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p1 = p0 + ppb < total ? p0 + ppb : total;
+    float acc[17];
+#pragma unroll
+    for (int t = 0; t < 17; ++t) acc[t] = 0.f;
+    for (int64_t pix = p0 + pl; pix < p1; pix += npl) {
+        const int ow = (int)(pix % Ho), oh = (int)((pix / Ho) % Ho), n = (int)(pix / ((int64_t)Ho * Ho));
+        const float* xp = seg_ptr(x0, n0, x1, n, S);
+        const float g = dv[(size_t)pix * C + co];
+        acc[16] += g;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int ih = 2 * oh - 1 + kh;
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int iw = 2 * ow - 1 + kw;
+                const float xv = ((unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) ? xp[ih * S + iw] : 0.f;
+                acc[kh * 4 + kw] = fmaf(g, xv, acc[kh * 4 + kw]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 17; ++t) sh[threadIdx.x * 17 + t] = acc[t];
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * (C * 17);
+    for (int o = threadIdx.x; o < C * 17; o += 256) {
+        // output order: [C*16 weights (co*16+tap)] then [C biases]
+        float s = 0.f;
+        int c, t;
+        if (o < C * 16) { c = o / 16; t = o % 16; } else { c = o - C * 16; t = 16; }
+        for (int k = 0; k < npl; ++k) s += sh[(k * C + c) * 17 + t];
+        out[o] = s;
+    }
+}
+void launch_conv1_wgrad(const float* dv, const float* x0, int n0, const float* x1, float* dW, float* db, float* partial,
+                        int B, int S, int C, hipStream_t s) {
+    const int64_t total = (int64_t)B * (S / 2) * (S / 2);
+    int nch = 1024;
+    int ppb = cdiv(total, nch);
+    ppb = ((ppb + 3) / 4) * 4;
+    nch = cdiv(total, ppb);
+    hipLaunchKernelGGL(k_conv1_wgrad, dim3(nch), dim3(256), 256 * 17 * sizeof(float), s, dv, x0, n0, x1, partial, B, S, C, ppb);
+    hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 17, 256)), dim3(256), 0, s, partial, nch, C * 17, dW, C * 16, db);
+}
+
+// 16 lanes per image pixel, 4 channels each; dpre = dimg * (1 - img^2)
+__global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const float* __restrict__ dv, const float* __restrict__ W,
+                                                          const float* __restrict__ img, float* __restrict__ dpre, int B,
+                                                          int S, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];   // [16][C]
+    for (int i = threadIdx.x; i < 16 * C; i += 256) sW[i] = W[(i % C) * 16 + i / C];
+    __syncthreads();
+    const int Ho = S / 2, Q = C / 4;              // host guarantees Q == 16
+    const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int64_t pix = (int64_t)blockIdx.x * 16 + pl;
+    const bool live = pix < (int64_t)B * S * S;
+    float acc = 0.f;
+    if (live) {
+        const int iw = (int)(pix % S), ih = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
+        const int kh0 = (ih + 1) & 1, kw0 = (iw + 1) & 1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int kh = kh0 + 2 * a, oh = (ih + 1 - kh) >> 1;
+            if ((ih + 1 - kh) < 0 || oh >= Ho) continue;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int kw = kw0 + 2 * bb, ow = (iw + 1 - kw) >> 1;
+                if ((iw + 1 - kw) < 0 || ow >= Ho) continue;
+                const float4 g = *(const float4*)(dv + (((size_t)n * Ho + oh) * Ho + ow) * C + q * 4);
+                const float4 wv = *(const float4*)(sW + (kh * 4 + kw) * C + q * 4);
+                acc = fmaf(g.x, wv.x, acc); acc = fmaf(g.y, wv.y, acc);
+                acc = fmaf(g.z, wv.z, acc); acc = fmaf(g.w, wv.w, acc);
+            }
+        }
+    }
+    (void)Q;
+    acc += __shfl_xor(acc, 8, 16); acc += __shfl_xor(acc, 4, 16);
+    acc += __shfl_xor(acc, 2, 16); acc += __shfl_xor(acc, 1, 16);
+    if (live && q == 0) {
+        const float t = img[pix];
+        dpre[pix] = acc * (1.0f - t * t);
+    }
+}
+void launch_conv1_dgrad_tanh(const float* dv, const float* W, const float* img, float* dpre, int B, int S, int C,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(k_conv1_dgrad_tanh, dim3(cdiv((int64_t)B * S * S, 16)), dim3(256), 16 * C * sizeof(float), s, dv, W,
+                       img, dpre, B, S, C);
+}
+
+// =========================================================================================
+// classifier, BCE
+// =========================================================================================
+__global__ void k_cls_pack(const float* __restrict__ Wc, float* __restrict__ wcp, int C) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;   // j = hw*C + c
+    if (j >= 16 * C) return;
+    wcp[j] = Wc[(j % C) * 16 + j / C];
+}
+void launch_cls_pack(const float* Wc, float* wcp, int C, hipStream_t s) {
+    hipLaunchKernelGGL(k_cls_pack, dim3(cdiv(16 * C, 256)), dim3(256), 0, s, Wc, wcp, C);
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += sh[k];
+    return s;
+}
+__global__ __launch_bounds__(256) void k_cls_fwd(const float* __restrict__ act, const float* __restrict__ wcp,
+                                                 const float* __restrict__ bc, float* __restrict__ logits, int F) {
+    __shared__ float sh[4];
+    const float4* a = (const float4*)(act + (size_t)blockIdx.x * F);
+    const float4* w = (const float4*)wcp;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < F / 4; i += 256) {
+        const float4 x = a[i], y = w[i];
+        acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+    }
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) logits[blockIdx.x] = s + bc[0];
+}
+void launch_cls_fwd(const float* act, const float* wcp, const float* bc, float* logits, int B, int F, hipStream_t s) {
+    hipLaunchKernelGGL(k_cls_fwd, dim3(B), dim3(256), 0, s, act, wcp, bc, logits, F);
+}
+__global__ void k_cls_features(const float* __restrict__ act, float* __restrict__ feat, int64_t total, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // i over [n][c][hw] (torch order)
+    if (i >= total) return;
+    const int hw = (int)(i % 16), c = (int)((i / 16) % C);
+    const int64_t n = i / (16 * (int64_t)C);
+    feat[i] = act[(n * 16 + hw) * C + c];
+}
+void launch_cls_features(const float* act, float* feat, int B, int C, hipStream_t s) {
+    const int64_t total = (int64_t)B * 16 * C;
+    hipLaunchKernelGGL(k_cls_features, dim3(cdiv(total, 256)), dim3(256), 0, s, act, feat, total, C);
+}
+
+// nn.Sigmoid + nn.BCELoss(mean) per segment and its gradient w.r.t. the logit (torch formulas:
+// log clamped at -100; grad_p = (p - y) / max((1 - p) * p, 1e-12) / count; dlogit = grad_p * p * (1 - p))
+__global__ __launch_bounds__(256) void k_bce(const float* __restrict__ logits, int B, int n0, float y0, float y1,
+                                             float* __restrict__ probs, float* __restrict__ dlogit,
+                                             float* __restrict__ metrics, int is_g) {
+    __shared__ float sh[4];
+    float l0 = 0.f, l1 = 0.f, p0 = 0.f, p1 = 0.f, a0 = 0.f, a1 = 0.f;
+    const float c0 = 1.0f / (float)(n0 > 0 ? n0 : 1), c1 = 1.0f / (float)(B - n0 > 0 ? B - n0 : 1);
+    for (int n = threadIdx.x; n < B; n += 256) {
+        const float x = logits[n];
+        const float p = 1.0f / (1.0f + expf(-x));
+        const bool s0 = n < n0;
+        const float y = s0 ? y0 : y1;
+        const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);
+        const float loss = -(y * lp + (1.0f - y) * lq);
+        const float gp = (p - y) / fmaxf((1.0f - p) * p, 1e-12f) * (s0 ? c0 : c1);
+        if (probs) probs[n] = p;
+        if (dlogit) dlogit[n] = gp * ((1.0f - p) * p);
+        if (s0) { l0 += loss; p0 += p; a0 += p > 0.5f ? 1.f : 0.f; }
+        else    { l1 += loss; p1 += p; a1 += p < 0.5f ? 1.f : 0.f; }
+    }
+    l0 = block_sum(l0, sh); l1 = block_sum(l1, sh); p0 = block_sum(p0, sh);
+    p1 = block_sum(p1, sh); a0 = block_sum(a0, sh); a1 = block_sum(a1, sh);
+    if (threadIdx.x == 0 && metrics) {
+        if (is_g) {
+            metrics[8] = l0 * c0;        // g_loss
+            metrics[9] = p0 * c0;        // g_fake_mean
+        } else {
+            metrics[1] = l0 * c0; metrics[2] = l1 * c1; metrics[0] = l0 * c0 + l1 * c1;
+            metrics[3] = p0 * c0; metrics[4] = p1 * c1; metrics[5] = a0 * c0; metrics[6] = a1 * c1;
+        }
+    }
+}
+void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* probs, float* dlogit, float* metrics,
+                int is_g_step, hipStream_t s) {
+    hipLaunchKernelGGL(k_bce, dim3(1), dim3(256), 0, s, logits, B, n0, y0, y1, probs, dlogit, metrics, is_g_step);
+}
+
+__global__ void k_cls_bwd(const float* __restrict__ dlogit, const float* __restrict__ wcp, const float* __restrict__ act,
+                          const float* __restrict__ noise, float slope, float* __restrict__ dv, int64_t total, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int F = 16 * C;
+    const int j = (int)(i % F), c = j % C;
+    const int64_t n = i / F;
+    float g = dlogit[n] * wcp[j] * (act[i] > 0.f ? 1.f : slope);
+    if (noise) g *= noise[n * C + c];
+    dv[i] = g;
+}
+void launch_cls_bwd(const float* dlogit, const float* wcp, const float* act, const float* noise, float slope, float* dv,
+                    int B, int C, hipStream_t s) {
+    const int64_t total = (int64_t)B * 16 * C;
+    hipLaunchKernelGGL(k_cls_bwd, dim3(cdiv(total, 256)), dim3(256), 0, s, dlogit, wcp, act, noise, slope, dv, total, C);
+}
+__global__ void k_cls_wgrad(const float* __restrict__ dlogit, const float* __restrict__ act, float* __restrict__ dWc,
+                            float* __restrict__ dbc, int B, int C) {
+    const int F = 16 * C;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > F) return;
+    float acc = 0.f;
+    if (j < F) {
+        for (int n = 0; n < B; ++n) acc = fmaf(dlogit[n], act[(size_t)n * F + j], acc);
+        dWc[(j % C) * 16 + j / C] = acc;
+    } else {
+        for (int n = 0; n < B; ++n) acc += dlogit[n];
+        dbc[0] = acc;
+    }
+}
+void launch_cls_wgrad(const float* dlogit, const float* act, float* dWc, float* dbc, int B, int C, hipStream_t s) {
+    hipLaunchKernelGGL(k_cls_wgrad, dim3(cdiv(16 * C + 1, 256)), dim3(256), 0, s, dlogit, act, dWc, dbc, B, C);
+}
+
+// =========================================================================================
+// clip + Adam
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_sumsq_fin(const float* __restrict__ partial, int nb, DevState* st) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) st->sumsq = s;
+}
+void launch_grad_sumsq(const float* g, int64_t n, DevState* st, float* partial, hipStream_t s) {
+    const int nb = 512;
+    hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, s, g, n, partial);
+    hipLaunchKernelGGL(k_sumsq_fin, dim3(1), dim3(256), 0, s, partial, nb, st);
+}
+
+__global__ void k_adam_prepare(DevState* st, float* __restrict__ steps, int ntensors, double lr, double beta1, double beta2,
+                               float grad_scale, float clip_max_norm, float* __restrict__ metric_norm) {
+    // torch.optim.Adam: step += 1; bias corrections as Python doubles (1 - beta**step)
+    const float t = steps[0] + 1.0f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntensors; i += blockDim.x) steps[i] = t;
+    if (threadIdx.x != 0) return;
+    const double bc1 = 1.0 - pow(beta1, (double)t);
+    const double bc2 = 1.0 - pow(beta2, (double)t);
+    st->step_size = (float)(lr / bc1);
+    st->bc2_sqrt = (float)sqrt(bc2);
+    float mul = grad_scale;
+    if (clip_max_norm > 0.f) {
+        const float norm = sqrtf(st->sumsq) * grad_scale;      // nn.utils.clip_grad_norm_ (norm_type 2)
+        const float coef = fminf(clip_max_norm / (norm + 1e-6f), 1.0f);
+        mul = grad_scale * coef;
+        st->grad_norm = norm;
+        if (metric_norm) *metric_norm = norm;
+    }
+    st->grad_mul = mul;
+}
+void launch_adam_prepare(DevState* st, float* steps, int ntensors, double lr, double beta1, double beta2, float grad_scale,
+                         float clip_max_norm, float* metric_norm, hipStream_t s) {
+    hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, s, st, steps, ntensors, lr, beta1, beta2, grad_scale,
+                       clip_max_norm, metric_norm);
+}
+
+__global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+                                              float4* __restrict__ v, int64_t n4, float* __restrict__ pt,
+                                              float* __restrict__ gt, float* __restrict__ mt, float* __restrict__ vt,
+                                              int tail, const DevState* __restrict__ st, float w1, float beta2,
+                                              float w2, float eps, int wb) {
+    // w1 = (float)(1 - beta1), w2 = (float)(1 - beta2): formed in double on the host, as torch does
+    const float mul = st->grad_mul, ss = -st->step_size, bc2 = st->bc2_sqrt;
+    auto upd = [&](float& pp, float& gg, float& mm, float& vv) {
+        const float gr = gg * mul;
+        gg = gr;
+        // exp_avg.lerp_(grad, 1 - beta1)
+        mm = w1 < 0.5f ? mm + w1 * (gr - mm) : gr - (gr - mm) * (1.0f - w1);
+        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        vv = vv * beta2 + w2 * gr * gr;
+        const float denom = sqrtf(vv) / bc2 + eps;
+        pp = pp + (ss * mm) / denom;
+    };
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y);
+        upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (wb) g[i] = gg;
+    } else if (i - n4 < tail) {
+        const int k = (int)(i - n4);
+        float pp = pt[k], gg = gt[k], mm = mt[k], vv = vt[k];
+        upd(pp, gg, mm, vv);
+        pt[k] = pp; mt[k] = mm; vt[k] = vv;
+        if (wb) gt[k] = gg;
+    }
+}
+void launch_adam(float* p, float* g, float* m, float* v, int64_t n, const DevState* st, double beta1, double beta2,
+                 double eps, int write_back_grad, hipStream_t s) {
+    const int64_t n4 = n / 4;
+    const int tail = (int)(n - n4 * 4);
+    hipLaunchKernelGGL(k_adam, dim3(cdiv(n4 + tail, 256)), dim3(256), 0, s, (float4*)p, (float4*)g, (float4*)m, (float4*)v,
+                       n4, p + n4 * 4, g + n4 * 4, m + n4 * 4, v + n4 * 4, tail, st, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps, write_back_grad);
+}
+
+}  // namespace siggan

@@ -1,0 +1,674 @@
+// siggan.hip -- C ABI (include/siggan.h) and step orchestration of the MI355X signature-GAN engine.
+//
+// One context = one GPU.  The caller (PyTorch-ROCm tensors, through ctypes) owns parameters,
+// gradients, Adam moments and BatchNorm buffers as flat fp32 arenas in the reference's
+// parameters() order; the library owns only the workspace allocated here (NHWC activations,
+// packed weight copies, split-K slabs, reduction partials, device-side step state).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "../../include/siggan.h"
+#include "gconv.h"
+#include "ops.h"
+
+using namespace siggan;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail(SIGGAN_E_HIP, "%s -> %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define LAUNCHCHK()                                                                                 \
+    do {                                                                                            \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) return fail(SIGGAN_E_HIP, "kernel launch -> %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static const float BN_MOMENTUM = 0.1f, BN_EPS = 1e-5f;   // nn.BatchNorm defaults (generator_vanilla_gan.py:58,126)
+static const int MAXL = 6;
+
+static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+struct siggan_ctx {
+    siggan_config cfg;
+    int S, latent, Lg, Ld, Bm;
+    int gC[MAXL + 1];   // generator channel chain gC[0..Lg]  (generator_vanilla_gan.py:131-149)
+    int dC[MAXL + 1];   // discriminator chain dC[0]=1, dC[1..Ld] (discriminator_vanilla_gan.py:131-194)
+    int F;              // gC[0]*16
+    // flat-arena spans (offset, numel) in parameters() order
+    std::vector<int64_t> g_off, g_num, d_off, d_num;
+    int64_t g_total, d_total, bn_total;
+    int64_t g_bn_off[MAXL + 1];
+    siggan_storage st;
+    bool bound;
+    bool g_dirty, d_dirty;
+    // workspace
+    char* ws; size_t ws_bytes;
+    float *z, *fc_y, *g_y[MAXL + 1], *g_a[MAXL + 1], *g_da[MAXL + 1], *g_bn[MAXL + 1];
+    float *img, *dpre;
+    float *d_a[MAXL + 1], *d_dv[MAXL + 1], *d_noise[MAXL + 1];
+    float *logits, *probs, *dlogit;
+    float *g_up[MAXL + 1], *g_dn[MAXL + 1], *d_dn[MAXL + 1], *d_up[MAXL + 1], *wcp;
+    float *slab, *partial, *metrics, *op_pack;
+    int64_t slab_floats;
+    DevState* dev;
+    // last *_grads call (for *_apply)
+    int pending;   // 0 none, 1 D, 2 G
+};
+
+// parameter tensor indices
+static inline int gi_fc_w() { return 0; }
+static inline int gi_fc_b() { return 1; }
+static inline int gi_bn0_w() { return 2; }
+static inline int gi_bn0_b() { return 3; }
+static inline int gi_up_w(int l) { return 4 + 3 * (l - 1); }       // l = 1..Lg
+static inline int gi_bn_w(int l) { return l == 0 ? 2 : 5 + 3 * (l - 1); }
+static inline int gi_bn_b(int l) { return l == 0 ? 3 : 6 + 3 * (l - 1); }
+static inline int gi_fin_w(const siggan_ctx* c) { return 4 + 3 * c->Lg; }
+static inline int gi_fin_b(const siggan_ctx* c) { return 5 + 3 * c->Lg; }
+static inline int di_w(int l) { return 2 * (l - 1); }              // l = 1..Ld
+static inline int di_b(int l) { return 2 * (l - 1) + 1; }
+static inline int di_cls_w(const siggan_ctx* c) { return 2 * c->Ld; }
+static inline int di_cls_b(const siggan_ctx* c) { return 2 * c->Ld + 1; }
+
+#define GP(c, i) ((c)->st.g_params + (c)->g_off[i])
+#define GG(c, i) ((c)->st.g_grads + (c)->g_off[i])
+#define DP(c, i) ((c)->st.d_params + (c)->d_off[i])
+#define DG(c, i) ((c)->st.d_grads + (c)->d_off[i])
+
+extern "C" int siggan_abi_version(void) { return SIGGAN_ABI_VERSION; }
+extern "C" const char* siggan_last_error(void) { return g_err; }
+
+static void build_layout(siggan_ctx* c) {
+    static const int g64[] = {256, 128, 64, 32, 32}, g128[] = {512, 256, 128, 64, 32, 32};
+    static const int d64[] = {1, 64, 128, 256, 512}, d128[] = {1, 64, 128, 256, 512, 512};
+    if (c->S == 64) { c->Lg = 4; c->Ld = 4; memcpy(c->gC, g64, sizeof g64); memcpy(c->dC, d64, sizeof d64); }
+    else            { c->Lg = 5; c->Ld = 5; memcpy(c->gC, g128, sizeof g128); memcpy(c->dC, d128, sizeof d128); }
+    c->F = c->gC[0] * 16;
+    auto push = [](std::vector<int64_t>& off, std::vector<int64_t>& num, int64_t& tot, int64_t n) {
+        off.push_back(tot); num.push_back(n); tot += n;
+    };
+    c->g_total = 0;
+    push(c->g_off, c->g_num, c->g_total, (int64_t)c->F * c->latent);
+    push(c->g_off, c->g_num, c->g_total, c->F);
+    push(c->g_off, c->g_num, c->g_total, c->F);
+    push(c->g_off, c->g_num, c->g_total, c->F);
+    for (int l = 1; l <= c->Lg; ++l) {
+        push(c->g_off, c->g_num, c->g_total, (int64_t)c->gC[l - 1] * c->gC[l] * 16);
+        push(c->g_off, c->g_num, c->g_total, c->gC[l]);
+        push(c->g_off, c->g_num, c->g_total, c->gC[l]);
+    }
+    push(c->g_off, c->g_num, c->g_total, (int64_t)c->gC[c->Lg] * 9);
+    push(c->g_off, c->g_num, c->g_total, 1);
+    c->d_total = 0;
+    for (int l = 1; l <= c->Ld; ++l) {
+        push(c->d_off, c->d_num, c->d_total, (int64_t)c->dC[l] * c->dC[l - 1] * 16);
+        push(c->d_off, c->d_num, c->d_total, c->dC[l]);
+    }
+    push(c->d_off, c->d_num, c->d_total, (int64_t)c->dC[c->Ld] * 16);
+    push(c->d_off, c->d_num, c->d_total, 1);
+    c->bn_total = 0;
+    c->g_bn_off[0] = 0; c->bn_total = c->F;
+    for (int l = 1; l <= c->Lg; ++l) { c->g_bn_off[l] = c->bn_total; c->bn_total += c->gC[l]; }
+}
+
+extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
+    if (!cfg || !out) return fail(SIGGAN_E_INVALID, "null argument");
+    if (cfg->image_size != 64 && cfg->image_size != 128)
+        return fail(SIGGAN_E_INVALID, "output_size must be 64 or 128, got %d", cfg->image_size);
+    if (cfg->image_channels != 1) return fail(SIGGAN_E_INVALID, "only image_channels == 1 is built, got %d", cfg->image_channels);
+    if (cfg->latent_dim < 1 || cfg->latent_dim > 4096) return fail(SIGGAN_E_INVALID, "latent_dim out of range: %d", cfg->latent_dim);
+    if (cfg->max_batch < 1 || cfg->max_batch > 4096) return fail(SIGGAN_E_INVALID, "max_batch out of range: %d", cfg->max_batch);
+    if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return fail(SIGGAN_E_INVALID, "dropout must be in [0,1)");
+    HIPCHK(hipSetDevice(cfg->device));
+    siggan_ctx* c = new (std::nothrow) siggan_ctx();
+    if (!c) return fail(SIGGAN_E_NOMEM, "out of host memory");
+    c->cfg = *cfg; c->S = cfg->image_size; c->latent = cfg->latent_dim; c->Bm = cfg->max_batch;
+    c->bound = false; c->g_dirty = c->d_dirty = true; c->pending = 0;
+    build_layout(c);
+
+    // ---- workspace carve (two passes: size, then assign) ----------------------------------
+    const int64_t Bm = c->Bm, Bd = 2 * Bm;
+    size_t off = 0;
+    char* base = nullptr;
+    auto carve = [&](float** p, int64_t nfloats) {
+        if (base) *p = (float*)(base + off);
+        off += ((size_t)nfloats * sizeof(float) + 255) & ~(size_t)255;
+    };
+    c->slab_floats = (int64_t)16 << 20;
+    for (int pass = 0; pass < 2; ++pass) {
+        off = 0;
+        carve(&c->z, Bm * c->latent);
+        carve(&c->fc_y, Bm * c->F);
+        for (int l = 0; l <= c->Lg; ++l) {
+            const int64_t H = 4 << l, n = Bm * H * H * c->gC[l];
+            if (l == 0) c->g_y[0] = c->fc_y; else carve(&c->g_y[l], n);
+            carve(&c->g_a[l], n);
+            carve(&c->g_da[l], n);
+            carve(&c->g_bn[l], 6 * (int64_t)(l == 0 ? c->F : c->gC[l]));
+        }
+        if (pass == 1) c->g_y[0] = c->fc_y;
+        carve(&c->img, Bm * c->S * c->S);
+        carve(&c->dpre, Bm * c->S * c->S);
+        for (int l = 1; l <= c->Ld; ++l) {
+            const int64_t H = c->S >> l, n = Bd * H * H * c->dC[l];
+            carve(&c->d_a[l], n);
+            carve(&c->d_dv[l], n);
+            carve(&c->d_noise[l], Bd * c->dC[l]);
+        }
+        carve(&c->logits, Bd); carve(&c->probs, Bd); carve(&c->dlogit, Bd);
+        for (int l = 1; l <= c->Lg; ++l) {
+            carve(&c->g_up[l], (int64_t)c->gC[l - 1] * c->gC[l] * 16);
+            carve(&c->g_dn[l], (int64_t)c->gC[l - 1] * c->gC[l] * 16);
+        }
+        for (int l = 2; l <= c->Ld; ++l) {
+            carve(&c->d_dn[l], (int64_t)c->dC[l - 1] * c->dC[l] * 16);
+            carve(&c->d_up[l], (int64_t)c->dC[l - 1] * c->dC[l] * 16);
+        }
+        carve(&c->wcp, (int64_t)c->dC[c->Ld] * 16);
+        carve(&c->slab, c->slab_floats);
+        carve(&c->partial, (int64_t)2 << 20);
+        carve(&c->metrics, SIGGAN_M_COUNT);
+        carve(&c->op_pack, (int64_t)512 * 512 * 16);
+        float* devp = nullptr;
+        carve(&devp, 64);
+        if (pass == 1) c->dev = (DevState*)devp;
+        if (pass == 0) {
+            c->ws_bytes = off;
+            hipError_t e = hipMalloc((void**)&base, off);
+            if (e != hipSuccess) { delete c; return fail(SIGGAN_E_NOMEM, "hipMalloc(%zu) -> %s", off, hipGetErrorString(e)); }
+            c->ws = base;
+        }
+    }
+    HIPCHK(hipMemset(c->ws, 0, c->ws_bytes));
+    DevState h; memset(&h, 0, sizeof h);
+    h.seed = cfg->seed; h.rng_ctr = 0; h.grad_mul = 1.f;
+    HIPCHK(hipMemcpy(c->dev, &h, sizeof h, hipMemcpyHostToDevice));
+    *out = c;
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_destroy(siggan_ctx* c) {
+    if (!c) return SIGGAN_OK;
+    hipSetDevice(c->cfg.device);
+    if (c->ws) hipFree(c->ws);
+    delete c;
+    return SIGGAN_OK;
+}
+
+extern "C" int64_t siggan_param_count(const siggan_ctx* c, int which) { return !c ? -1 : (which == 0 ? c->g_total : c->d_total); }
+extern "C" int32_t siggan_param_tensors(const siggan_ctx* c, int which) {
+    return !c ? -1 : (int32_t)(which == 0 ? c->g_off.size() : c->d_off.size());
+}
+extern "C" int siggan_param_span(const siggan_ctx* c, int which, int32_t idx, int64_t* offset, int64_t* numel) {
+    if (!c || !offset || !numel) return fail(SIGGAN_E_INVALID, "null argument");
+    const auto& o = which == 0 ? c->g_off : c->d_off;
+    const auto& n = which == 0 ? c->g_num : c->d_num;
+    if (idx < 0 || idx >= (int32_t)o.size()) return fail(SIGGAN_E_INVALID, "tensor index %d out of range", idx);
+    *offset = o[idx]; *numel = n[idx];
+    return SIGGAN_OK;
+}
+extern "C" int64_t siggan_bn_count(const siggan_ctx* c) { return c ? c->bn_total : -1; }
+extern "C" int32_t siggan_bn_layers(const siggan_ctx* c) { return c ? c->Lg + 1 : -1; }
+extern "C" int64_t siggan_workspace_bytes(const siggan_ctx* c) { return c ? (int64_t)c->ws_bytes : -1; }
+
+extern "C" int siggan_bind(siggan_ctx* c, const siggan_storage* st) {
+    if (!c || !st) return fail(SIGGAN_E_INVALID, "null argument");
+    const void* need[] = {st->g_params, st->g_bn_running_mean, st->g_bn_running_var, st->d_params};
+    for (const void* p : need)
+        if (!p) return fail(SIGGAN_E_INVALID, "siggan_bind: parameters and BatchNorm buffers are required");
+    const void* all[] = {st->g_params, st->g_grads, st->g_exp_avg, st->g_exp_avg_sq, st->d_params, st->d_grads,
+                         st->d_exp_avg, st->d_exp_avg_sq};
+    for (const void* p : all)
+        if (((uintptr_t)p & 15) != 0) return fail(SIGGAN_E_INVALID, "siggan_bind: arenas must be 16-byte aligned");
+    c->st = *st;
+    c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0;
+    return SIGGAN_OK;
+}
+extern "C" int siggan_params_changed(siggan_ctx* c) {
+    if (!c) return fail(SIGGAN_E_INVALID, "null context");
+    c->g_dirty = c->d_dirty = true;
+    return SIGGAN_OK;
+}
+extern "C" int siggan_seed(siggan_ctx* c, uint64_t seed, uint64_t offset) {
+    if (!c) return fail(SIGGAN_E_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    unsigned long long v[2] = {seed, offset};
+    HIPCHK(hipMemcpy(c->dev, v, sizeof v, hipMemcpyHostToDevice));   // seed, rng_ctr are the first two fields
+    return SIGGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// internal passes
+// ------------------------------------------------------------------------------------------
+static int check_call(siggan_ctx* c, int batch, bool need_bound = true) {
+    if (!c) return fail(SIGGAN_E_INVALID, "null context");
+    if (need_bound && !c->bound) return fail(SIGGAN_E_STATE, "siggan_bind has not been called");
+    if (batch < 1 || batch > c->Bm) return fail(SIGGAN_E_INVALID, "batch %d outside [1, max_batch=%d]", batch, c->Bm);
+    hipError_t e = hipSetDevice(c->cfg.device);
+    if (e != hipSuccess) return fail(SIGGAN_E_HIP, "hipSetDevice -> %s", hipGetErrorString(e));
+    return SIGGAN_OK;
+}
+
+static void repack(siggan_ctx* c, hipStream_t s) {
+    if (c->g_dirty) {
+        for (int l = 1; l <= c->Lg; ++l) {
+            const float* w = GP(c, gi_up_w(l));                       // (Cin, Cout, 4, 4)
+            launch_pack_up(w, c->g_up[l], c->gC[l - 1], c->gC[l], s);   // forward: contract Cin
+            launch_pack_down(w, c->g_dn[l], c->gC[l - 1], c->gC[l], s); // input-gradient: out = Cin, contract Cout
+        }
+        c->g_dirty = false;
+    }
+    if (c->d_dirty) {
+        for (int l = 2; l <= c->Ld; ++l) {
+            const float* w = DP(c, di_w(l));                          // (Cout, Cin, 4, 4)
+            launch_pack_down(w, c->d_dn[l], c->dC[l], c->dC[l - 1], s); // forward
+            launch_pack_up(w, c->d_up[l], c->dC[l], c->dC[l - 1], s);   // input-gradient: contract Cout, produce Cin
+        }
+        launch_cls_pack(DP(c, di_cls_w(c)), c->wcp, c->dC[c->Ld], s);
+        c->d_dirty = false;
+    }
+}
+
+// Generator.forward (generator_vanilla_gan.py:189-209).  training: BN batch stats (+ running
+// update) and raw pre-BN outputs kept for the backward pass; eval: BN folded into the epilogue.
+static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s) {
+    const float* rm = c->st.g_bn_running_mean; const float* rv = c->st.g_bn_running_var;
+    launch_fc_fwd(z, GP(c, gi_fc_w()), GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s);
+    if (training)
+        launch_bn_train_stats(c->fc_y, B, c->F, GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), c->st.g_bn_running_mean,
+                              c->st.g_bn_running_var, c->st.g_bn_batches, c->g_bn[0], c->partial, c->gC[0], BN_MOMENTUM,
+                              BN_EPS, s);
+    else
+        launch_bn_eval_affine(GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), rm, rv, c->g_bn[0], c->F, c->gC[0], BN_EPS, s);
+    launch_bn_relu(c->fc_y, c->g_a[0], B, c->F, c->g_bn[0], s);
+    for (int l = 1; l <= c->Lg; ++l) {
+        const int Hi = 4 << (l - 1), Ci = c->gC[l - 1], Co = c->gC[l];
+        GConvArgs a; memset(&a, 0, sizeof a);
+        a.in = c->g_a[l - 1]; a.wp = c->g_up[l]; a.B = B; a.Hi = Hi; a.Wi = Hi; a.Ci = Ci; a.Co = Co;
+        a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = 2 * Hi; a.Wo = 2 * Hi; a.form = 1; a.M = B * Hi * Hi;
+        const int C = Co;
+        const int64_t off = c->g_bn_off[l];
+        if (training) {
+            a.out = c->g_y[l]; a.epi = EPI_RAW;
+            launch_gconv(a, s);
+            const int64_t R = (int64_t)B * 4 * Hi * Hi;
+            launch_bn_train_stats(c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
+                                  c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], c->partial, 0,
+                                  BN_MOMENTUM, BN_EPS, s);
+            launch_bn_relu(c->g_y[l], c->g_a[l], R, C, c->g_bn[l], s);
+        } else {
+            launch_bn_eval_affine(GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), rm + off, rv + off, c->g_bn[l], C, 0, BN_EPS, s);
+            a.out = c->g_a[l]; a.epi = EPI_AFFINE_RELU; a.scale = c->g_bn[l]; a.shift = c->g_bn[l] + C;
+            launch_gconv(a, s);
+        }
+    }
+    launch_final_fwd(c->g_a[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
+}
+
+// Discriminator conv blocks + classifier logits over Bd images given as two segments.
+static void d_forward_pass(siggan_ctx* c, const float* x0, int n0, const float* x1, int Bd, bool dropout, hipStream_t s) {
+    const float slope = c->cfg.leaky_slope;
+    launch_conv1_fwd(x0, n0, x1, DP(c, di_w(1)), DP(c, di_b(1)), dropout ? c->d_noise[1] : nullptr, slope, c->d_a[1], Bd,
+                     c->S, c->dC[1], s);
+    for (int l = 2; l <= c->Ld; ++l) {
+        const int Hi = c->S >> (l - 1), Ho = Hi / 2;
+        GConvArgs a; memset(&a, 0, sizeof a);
+        a.in = c->d_a[l - 1]; a.wp = c->d_dn[l]; a.out = c->d_a[l];
+        a.B = Bd; a.Hi = Hi; a.Wi = Hi; a.Ci = c->dC[l - 1]; a.Co = c->dC[l];
+        a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Ho; a.Wo = Ho; a.form = 0; a.M = Bd * Ho * Ho;
+        a.epi = EPI_BIAS_LRELU_DROP; a.bias = DP(c, di_b(l)); a.noise = dropout ? c->d_noise[l] : nullptr; a.slope = slope;
+        launch_gconv(a, s);
+    }
+    launch_cls_fwd(c->d_a[c->Ld], c->wcp, DP(c, di_cls_b(c)), c->logits, Bd, c->dC[c->Ld] * 16, s);
+}
+
+// Backward through the Discriminator from d(logit).  want_wgrad: fill the D gradient arena
+// (D step); want_dimage: continue to d(pre-tanh image) (G step).
+static void d_backward_pass(siggan_ctx* c, const float* x0, int n0, const float* x1, int Bd, bool dropout,
+                            bool want_wgrad, bool want_dimage, hipStream_t s) {
+    const float slope = c->cfg.leaky_slope;
+    const int L = c->Ld;
+    launch_cls_bwd(c->dlogit, c->wcp, c->d_a[L], dropout ? c->d_noise[L] : nullptr, slope, c->d_dv[L], Bd, c->dC[L], s);
+    if (want_wgrad) launch_cls_wgrad(c->dlogit, c->d_a[L], DG(c, di_cls_w(c)), DG(c, di_cls_b(c)), Bd, c->dC[L], s);
+    for (int l = L; l >= 2; --l) {
+        const int Ho = c->S >> l, Hi = 2 * Ho, Co = c->dC[l], Ci = c->dC[l - 1];
+        if (want_wgrad) {
+            WgradArgs w; memset(&w, 0, sizeof w);
+            w.S = c->d_dv[l]; w.L = c->d_a[l - 1]; w.slab = c->slab; w.B = Bd; w.Cs = Co; w.Cl = Ci;
+            w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
+            const int max_splits = (int)(c->slab_floats / ((int64_t)Co * 16 * Ci));
+            const int ns = launch_wgrad(w, max_splits, s);
+            launch_wgrad_reduce(c->slab, DG(c, di_w(l)), ns, Co, Ci, s);
+            launch_colsum(c->d_dv[l], (int64_t)Bd * Ho * Ho, Co, DG(c, di_b(l)), c->partial, s);
+        }
+        // input gradient ("up" form): contract Cout, produce Cin at (Hi x Hi); fused leaky'/dropout of block l-1
+        GConvArgs a; memset(&a, 0, sizeof a);
+        a.in = c->d_dv[l]; a.wp = c->d_up[l]; a.out = c->d_dv[l - 1];
+        a.B = Bd; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
+        a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 1; a.M = Bd * Ho * Ho;
+        a.epi = EPI_LRELU_BWD; a.aref = c->d_a[l - 1]; a.noise = dropout ? c->d_noise[l - 1] : nullptr; a.slope = slope;
+        launch_gconv(a, s);
+    }
+    if (want_wgrad)
+        launch_conv1_wgrad(c->d_dv[1], x0, n0, x1, DG(c, di_w(1)), DG(c, di_b(1)), c->partial, Bd, c->S, c->dC[1], s);
+    if (want_dimage)
+        launch_conv1_dgrad_tanh(c->d_dv[1], DP(c, di_w(1)), x0, c->dpre, Bd, c->S, c->dC[1], s);
+}
+
+// Backward through the Generator from d(pre-tanh) in c->dpre; fills the G gradient arena.
+static void g_backward_pass(siggan_ctx* c, const float* z, int B, hipStream_t s) {
+    const int Lg = c->Lg, S = c->S;
+    launch_final_wgrad(c->dpre, c->g_a[Lg], GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), c->partial, B, S, c->gC[Lg], s);
+    launch_final_dgrad(c->dpre, GP(c, gi_fin_w(c)), c->g_da[Lg], B, S, c->gC[Lg], s);
+    for (int l = Lg; l >= 1; --l) {
+        const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
+        const int64_t R = (int64_t)B * Ho * Ho;
+        launch_bn_bwd(c->g_da[l], c->g_y[l], c->g_a[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, s);
+        // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
+        WgradArgs w; memset(&w, 0, sizeof w);
+        w.S = c->g_a[l - 1]; w.L = c->g_da[l]; w.slab = c->slab; w.B = B; w.Cs = Ci; w.Cl = Co;
+        w.lgHs = ilog2i(Hi); w.lgWs = w.lgHs; w.lgCl = ilog2i(Co); w.K = B * Hi * Hi;
+        const int max_splits = (int)(c->slab_floats / ((int64_t)Ci * 16 * Co));
+        const int ns = launch_wgrad(w, max_splits, s);
+        launch_wgrad_reduce(c->slab, GG(c, gi_up_w(l)), ns, Ci, Co, s);
+        // input gradient ("down" form): out = Cin at Hi, contract Cout over 16 taps
+        GConvArgs a; memset(&a, 0, sizeof a);
+        a.in = c->g_da[l]; a.wp = c->g_dn[l]; a.out = c->g_da[l - 1];
+        a.B = B; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
+        a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
+        launch_gconv(a, s);
+    }
+    launch_bn_bwd(c->g_da[0], c->fc_y, c->g_a[0], B, c->F, c->g_bn[0], c->partial, GG(c, gi_bn0_w()), GG(c, gi_bn0_b()),
+                  c->gC[0], s);
+    launch_fc_wgrad(c->g_da[0], z, GG(c, gi_fc_w()), GG(c, gi_fc_b()), B, c->latent, c->gC[0], s);
+}
+
+static void make_noise(siggan_ctx* c, const float* masks, int B, int passes, hipStream_t s) {
+    const float keep = 1.0f - c->cfg.dropout;
+    int64_t sumC = 0;
+    for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l];
+    int64_t pre = 0;
+    for (int l = 1; l <= c->Ld; ++l) {
+        const int64_t n = (int64_t)B * c->dC[l];
+        if (masks) {
+            for (int p = 0; p < passes; ++p)
+                launch_mask_to_noise(masks + (int64_t)p * B * sumC + (int64_t)B * pre, c->d_noise[l] + p * n, n, keep, s);
+        } else {
+            launch_dropnoise(c->d_noise[l], n * passes, keep, c->dev, 16 + l, s);
+        }
+        pre += c->dC[l];
+    }
+}
+
+static int finish_metrics(siggan_ctx* c, float* metrics_dev, float* metrics_host, hipStream_t s) {
+    if (metrics_dev) HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (metrics_host) {
+        HIPCHK(hipMemcpyAsync(metrics_host, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return SIGGAN_OK;
+}
+
+static int check_hyper(const siggan_hyper* hp) {
+    if (!hp) return fail(SIGGAN_E_INVALID, "null hyper-parameters");
+    if (!(hp->lr >= 0.0) || !(hp->beta1 >= 0.0 && hp->beta1 < 1.0) || !(hp->beta2 >= 0.0 && hp->beta2 < 1.0) || !(hp->eps >= 0.0))
+        return fail(SIGGAN_E_INVALID, "invalid Adam hyper-parameters");
+    return SIGGAN_OK;
+}
+
+static int apply_adam(siggan_ctx* c, int which, const siggan_hyper* hp, hipStream_t s) {
+    float* p = which == 0 ? c->st.g_params : c->st.d_params;
+    float* g = which == 0 ? c->st.g_grads : c->st.d_grads;
+    float* m = which == 0 ? c->st.g_exp_avg : c->st.d_exp_avg;
+    float* v = which == 0 ? c->st.g_exp_avg_sq : c->st.d_exp_avg_sq;
+    float* steps = which == 0 ? c->st.g_adam_steps : c->st.d_adam_steps;
+    const int64_t n = which == 0 ? c->g_total : c->d_total;
+    const int nt = (int)(which == 0 ? c->g_off.size() : c->d_off.size());
+    if (!g || !m || !v || !steps) return fail(SIGGAN_E_STATE, "gradient / Adam arenas were not bound");
+    const bool clip = hp->clip_max_norm > 0.f;
+    const float gs = hp->grad_scale > 0.f ? hp->grad_scale : 1.0f;
+    if (clip) launch_grad_sumsq(g, n, c->dev, c->partial, s);
+    launch_adam_prepare(c->dev, steps, nt, hp->lr, hp->beta1, hp->beta2, gs, hp->clip_max_norm,
+                        c->metrics + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), s);
+    launch_adam(p, g, m, v, n, c->dev, hp->beta1, hp->beta2, hp->eps, (clip || gs != 1.0f) ? 1 : 0, s);
+    if (which == 0) c->g_dirty = true; else c->d_dirty = true;
+    LAUNCHCHK();
+    return SIGGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// public passes
+// ------------------------------------------------------------------------------------------
+extern "C" int siggan_g_forward(siggan_ctx* c, const float* z_dev, int32_t batch, int32_t training, float* images_dev,
+                                void* stream) {
+    int rc = check_call(c, batch);
+    if (rc) return rc;
+    if (!z_dev || !images_dev) return fail(SIGGAN_E_INVALID, "null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    repack(c, s);
+    g_forward_pass(c, z_dev, batch, training != 0, images_dev, s);
+    LAUNCHCHK();
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_d_forward(siggan_ctx* c, const float* x_dev, int32_t batch, int32_t training, const float* masks_dev,
+                                float* probs_dev, float* features_dev, void* stream) {
+    int rc = check_call(c, batch);
+    if (rc) return rc;
+    if (!x_dev || (!probs_dev && !features_dev)) return fail(SIGGAN_E_INVALID, "null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    repack(c, s);
+    const bool drop = training != 0 && c->cfg.dropout > 0.f;
+    if (drop) { if (!masks_dev) launch_tick(c->dev, s); make_noise(c, masks_dev, batch, 1, s); }
+    d_forward_pass(c, x_dev, batch, x_dev, batch, drop, s);
+    if (probs_dev) launch_bce(c->logits, batch, batch, 0.f, 0.f, probs_dev, nullptr, nullptr, 0, s);
+    if (features_dev) launch_cls_features(c->d_a[c->Ld], features_dev, batch, c->dC[c->Ld], s);
+    LAUNCHCHK();
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_d_grads(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
+                              const siggan_hyper* hp, float* metrics_dev, void* stream) {
+    int rc = check_call(c, batch);
+    if (rc) return rc;
+    if ((rc = check_hyper(hp))) return rc;
+    if (!real_dev) return fail(SIGGAN_E_INVALID, "null real batch");
+    if (!c->st.d_grads) return fail(SIGGAN_E_STATE, "gradient arena was not bound");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = batch;
+    repack(c, s);
+    launch_tick(c->dev, s);
+    const float* z = z_dev;
+    if (!z) { launch_randn(c->z, (int64_t)B * c->latent, c->dev, 1, s); z = c->z; }
+    const bool drop = c->cfg.dropout > 0.f;
+    if (drop) make_noise(c, masks_dev, B, 2, s);
+    g_forward_pass(c, z, B, false, c->img, s);                       // G.eval(), no grad (train...py:314-315)
+    d_forward_pass(c, real_dev, B, c->img, 2 * B, drop, s);          // D(real) and D(fake) as one 2B batch
+    launch_bce(c->logits, 2 * B, B, hp->label_smoothing, 0.f, c->probs, c->dlogit, c->metrics, 0, s);
+    d_backward_pass(c, real_dev, B, c->img, 2 * B, drop, true, false, s);
+    LAUNCHCHK();
+    c->pending = 1;
+    if (metrics_dev) HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_d_apply(siggan_ctx* c, const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
+    int rc = check_call(c, 1);
+    if (rc) return rc;
+    if ((rc = check_hyper(hp))) return rc;
+    if (c->pending != 1) return fail(SIGGAN_E_STATE, "siggan_d_apply without a preceding siggan_d_grads");
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = apply_adam(c, 1, hp, s))) return rc;
+    c->pending = 0;
+    return finish_metrics(c, metrics_dev, metrics_host, s);
+}
+
+extern "C" int siggan_d_step(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
+                             const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
+    int rc = siggan_d_grads(c, real_dev, batch, z_dev, masks_dev, hp, nullptr, stream);
+    if (rc) return rc;
+    return siggan_d_apply(c, hp, metrics_dev, metrics_host, stream);
+}
+
+extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, const siggan_hyper* hp, float* metrics_dev,
+                              void* stream) {
+    int rc = check_call(c, batch);
+    if (rc) return rc;
+    if ((rc = check_hyper(hp))) return rc;
+    if (!c->st.g_grads) return fail(SIGGAN_E_STATE, "gradient arena was not bound");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = batch;
+    repack(c, s);
+    launch_tick(c->dev, s);
+    const float* z = z_dev;
+    if (!z) { launch_randn(c->z, (int64_t)B * c->latent, c->dev, 2, s); z = c->z; }
+    else if (z != c->z) {
+        HIPCHK(hipMemcpyAsync(c->z, z, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
+        z = c->z;
+    }
+    g_forward_pass(c, z, B, true, c->img, s);                        // G.train(): BN batch stats (train...py:349)
+    d_forward_pass(c, c->img, B, c->img, B, false, s);               // D.eval(): dropout off (train...py:350)
+    launch_bce(c->logits, B, B, 1.0f, 1.0f, c->probs, c->dlogit, c->metrics, 1, s);
+    d_backward_pass(c, c->img, B, c->img, B, false, false, true, s); // through D into the image; no D weight grads
+    g_backward_pass(c, z, B, s);
+    LAUNCHCHK();
+    c->pending = 2;
+    if (metrics_dev) HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_g_apply(siggan_ctx* c, const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
+    int rc = check_call(c, 1);
+    if (rc) return rc;
+    if ((rc = check_hyper(hp))) return rc;
+    if (c->pending != 2) return fail(SIGGAN_E_STATE, "siggan_g_apply without a preceding siggan_g_grads");
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = apply_adam(c, 0, hp, s))) return rc;
+    c->pending = 0;
+    return finish_metrics(c, metrics_dev, metrics_host, s);
+}
+
+extern "C" int siggan_g_step(siggan_ctx* c, int32_t batch, const float* z_dev, const siggan_hyper* hp, float* metrics_dev,
+                             float* metrics_host, void* stream) {
+    int rc = siggan_g_grads(c, batch, z_dev, hp, nullptr, stream);
+    if (rc) return rc;
+    return siggan_g_apply(c, hp, metrics_dev, metrics_host, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// operator-level entry points
+// ------------------------------------------------------------------------------------------
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" int siggan_op_conv4x4s2(siggan_ctx* c, int32_t form, const float* in_dev, const float* w_dev, float* out_dev,
+                                   int32_t batch, int32_t h_in, int32_t c_in, int32_t c_out, void* stream) {
+    if (!c) return fail(SIGGAN_E_INVALID, "null context");
+    if (!in_dev || !w_dev || !out_dev) return fail(SIGGAN_E_INVALID, "null tensor");
+    if (form != 0 && form != 1) return fail(SIGGAN_E_INVALID, "form must be 0 (down) or 1 (up)");
+    if (!pow2(h_in) || !pow2(c_in) || !pow2(c_out) || c_in < 32 || c_out < 32 || c_in > 512 || c_out > 512 || batch < 1)
+        return fail(SIGGAN_E_INVALID, "shape not in the model family (pow2 dims, 32 <= C <= 512)");
+    if (form == 0 && h_in < 2) return fail(SIGGAN_E_INVALID, "down form needs h_in >= 2");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    GConvArgs a; memset(&a, 0, sizeof a);
+    a.in = in_dev; a.wp = c->op_pack; a.out = out_dev; a.B = batch; a.Hi = h_in; a.Wi = h_in; a.Ci = c_in; a.Co = c_out;
+    a.form = form; a.epi = EPI_RAW;
+    if (form == 0) {
+        launch_pack_down(w_dev, c->op_pack, c_out, c_in, s);
+        a.Ho = a.Wo = h_in / 2; a.lgHr = a.lgWr = ilog2i(h_in / 2); a.M = batch * (h_in / 2) * (h_in / 2);
+    } else {
+        launch_pack_up(w_dev, c->op_pack, c_in, c_out, s);
+        a.Ho = a.Wo = 2 * h_in; a.lgHr = a.lgWr = ilog2i(h_in); a.M = batch * h_in * h_in;
+    }
+    launch_gconv(a, s);
+    LAUNCHCHK();
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_op_conv4x4s2_wgrad(siggan_ctx* c, const float* small_dev, const float* large_dev, float* dw_dev,
+                                         int32_t batch, int32_t h_small, int32_t c_small, int32_t c_large, void* stream) {
+    if (!c) return fail(SIGGAN_E_INVALID, "null context");
+    if (!small_dev || !large_dev || !dw_dev) return fail(SIGGAN_E_INVALID, "null tensor");
+    if (!pow2(h_small) || !pow2(c_small) || !pow2(c_large) || c_small < 32 || c_large < 32 || c_small > 512 || c_large > 512 ||
+        batch < 1)
+        return fail(SIGGAN_E_INVALID, "shape not in the model family (pow2 dims, 32 <= C <= 512)");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    WgradArgs w; memset(&w, 0, sizeof w);
+    w.S = small_dev; w.L = large_dev; w.slab = c->slab; w.B = batch; w.Cs = c_small; w.Cl = c_large;
+    w.lgHs = w.lgWs = ilog2i(h_small); w.lgCl = ilog2i(c_large); w.K = batch * h_small * h_small;
+    const int max_splits = (int)(c->slab_floats / ((int64_t)c_small * 16 * c_large));
+    const int ns = launch_wgrad(w, max_splits, s);
+    launch_wgrad_reduce(c->slab, dw_dev, ns, c_small, c_large, s);
+    LAUNCHCHK();
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_op_adam(siggan_ctx* c, float* p, float* g, float* m, float* v, int64_t n, int32_t step,
+                              const siggan_hyper* hp, void* stream) {
+    if (!c) return fail(SIGGAN_E_INVALID, "null context");
+    int rc = check_hyper(hp);
+    if (rc) return rc;
+    if (!p || !g || !m || !v || n < 1 || step < 1) return fail(SIGGAN_E_INVALID, "bad argument");
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return fail(SIGGAN_E_INVALID, "arenas must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    float* steps = c->partial + ((2 << 20) - 64);          // scratch slot: step count before the increment
+    const float prev = (float)(step - 1);
+    HIPCHK(hipMemcpyAsync(steps, &prev, sizeof prev, hipMemcpyHostToDevice, s));
+    const bool clip = hp->clip_max_norm > 0.f;
+    const float gs = hp->grad_scale > 0.f ? hp->grad_scale : 1.0f;
+    if (clip) launch_grad_sumsq(g, n, c->dev, c->partial, s);
+    launch_adam_prepare(c->dev, steps, 1, hp->lr, hp->beta1, hp->beta2, gs, hp->clip_max_norm, nullptr, s);
+    launch_adam(p, g, m, v, n, c->dev, hp->beta1, hp->beta2, hp->eps, (clip || gs != 1.0f) ? 1 : 0, s);
+    LAUNCHCHK();
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_debug_tensor(siggan_ctx* c, const char* name, int32_t idx, float* out_dev, int64_t n, void* stream) {
+    if (!c || !name || !out_dev || n < 1) return fail(SIGGAN_E_INVALID, "bad argument");
+    float* src = nullptr; int64_t capv = 0;
+    float** ptr = &src; int64_t* cap = &capv;
+    const int64_t Bm = c->Bm, Bd = 2 * Bm, SS = (int64_t)c->S * c->S;
+    auto gsz = [&](int l) { const int64_t H = 4 << l; return Bm * H * H * c->gC[l]; };
+    auto dsz = [&](int l) { const int64_t H = c->S >> l; return Bd * H * H * c->dC[l]; };
+    const bool gl = idx >= 0 && idx <= c->Lg, dl = idx >= 1 && idx <= c->Ld;
+    if (!strcmp(name, "g_y") && gl) { *ptr = c->g_y[idx]; *cap = gsz(idx); }
+    else if (!strcmp(name, "g_a") && gl) { *ptr = c->g_a[idx]; *cap = gsz(idx); }
+    else if (!strcmp(name, "g_da") && gl) { *ptr = c->g_da[idx]; *cap = gsz(idx); }
+    else if (!strcmp(name, "d_a") && dl) { *ptr = c->d_a[idx]; *cap = dsz(idx); }
+    else if (!strcmp(name, "d_dv") && dl) { *ptr = c->d_dv[idx]; *cap = dsz(idx); }
+    else if (!strcmp(name, "img")) { *ptr = c->img; *cap = Bm * SS; }
+    else if (!strcmp(name, "dpre")) { *ptr = c->dpre; *cap = Bm * SS; }
+    else if (!strcmp(name, "logits")) { *ptr = c->logits; *cap = Bd; }
+    else if (!strcmp(name, "probs")) { *ptr = c->probs; *cap = Bd; }
+    else if (!strcmp(name, "dlogit")) { *ptr = c->dlogit; *cap = Bd; }
+    else return fail(SIGGAN_E_INVALID, "unknown debug tensor %s[%d]", name, idx);
+    if (n > capv) return fail(SIGGAN_E_INVALID, "debug tensor %s[%d] holds %lld floats, %lld asked", name, idx, (long long)capv, (long long)n);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpyAsync(out_dev, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_op_randn(siggan_ctx* c, float* out_dev, int64_t n, void* stream) {
+    if (!c || !out_dev || n < 1) return fail(SIGGAN_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    launch_tick(c->dev, s);
+    launch_randn(out_dev, n, c->dev, 3, s);
+    LAUNCHCHK();
+    return SIGGAN_OK;
+}

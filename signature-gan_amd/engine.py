@@ -1,0 +1,252 @@
+"""Host-side context of the HIP engine: owns the torch flat arenas the C ABI borrows and exposes
+the step / forward calls.  PyTorch here is plumbing only (device memory, streams)."""
+import ctypes as C
+
+import torch
+
+from . import _lib, layout
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32(t, device, what):
+    if t is None:
+        return None
+    if t.device != device:
+        raise ValueError(f"{what} must live on {device}, got {t.device}")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{what} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class Engine:
+    """One MI355X context for a (latent_dim, image_size) model.
+
+    Arenas (all on ``device``): ``g_params/g_grads/g_exp_avg/g_exp_avg_sq`` and the ``d_*``
+    equivalents are flat fp32 tensors in the reference's parameters() order; ``g_views`` /
+    ``d_views`` map state_dict keys to views into them (so ``state_dict()`` / checkpoints need
+    no conversion)."""
+
+    def __init__(self, latent_dim=100, image_size=64, max_batch=64, device="cuda:0", seed=0,
+                 dropout=0.25, leaky_slope=0.2, image_channels=1):
+        layout.check_size(image_size)
+        if image_channels != 1:
+            raise ValueError(f"only image_channels == 1 is built, got {image_channels}")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the HIP engine needs a ROCm device ('cuda:N'); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = _lib.load()
+        self.latent_dim, self.image_size, self.max_batch = int(latent_dim), int(image_size), int(max_batch)
+        self.dropout = float(dropout)
+        cfg = _lib.Config(self.device.index, self.latent_dim, self.image_size, image_channels, self.max_batch,
+                          dropout, leaky_slope, seed)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.siggan_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.g_entries = layout.generator_entries(latent_dim, image_size)
+        self.d_entries = layout.discriminator_entries(image_size)
+        self.g_spans, g_total = layout.spans(self.g_entries)
+        self.d_spans, d_total = layout.spans(self.d_entries)
+        self.bn_spans, bn_total = layout.spans(self.g_entries, "bn_mean")
+        assert g_total == self.lib.siggan_param_count(h, 0) and d_total == self.lib.siggan_param_count(h, 1)
+        assert bn_total == self.lib.siggan_bn_count(h)
+        for which, sp in ((0, self.g_spans), (1, self.d_spans)):
+            assert len(sp) == self.lib.siggan_param_tensors(h, which)
+            o, n = C.c_int64(), C.c_int64()
+            for i, (off, num, _) in enumerate(sp.values()):
+                _lib.check(self.lib.siggan_param_span(h, which, i, C.byref(o), C.byref(n)))
+                assert (o.value, n.value) == (off, num), "host/library layout mismatch"
+        dev, z = self.device, lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device)
+        self.g_params, self.g_grads, self.g_exp_avg, self.g_exp_avg_sq = z(g_total), z(g_total), z(g_total), z(g_total)
+        self.d_params, self.d_grads, self.d_exp_avg, self.d_exp_avg_sq = z(d_total), z(d_total), z(d_total), z(d_total)
+        self.g_adam_steps, self.d_adam_steps = z(len(self.g_spans)), z(len(self.d_spans))
+        self.g_bn_mean, self.g_bn_var = z(bn_total), torch.ones(bn_total, dtype=torch.float32, device=dev)
+        self.g_bn_batches = z(len(self.bn_spans), torch.int64)
+        self.metrics = z(_lib.M_COUNT)
+        st = _lib.Storage(*[t.data_ptr() for t in (
+            self.g_params, self.g_grads, self.g_exp_avg, self.g_exp_avg_sq, self.g_adam_steps, self.g_bn_mean,
+            self.g_bn_var, self.g_bn_batches, self.d_params, self.d_grads, self.d_exp_avg, self.d_exp_avg_sq,
+            self.d_adam_steps)])
+        _lib.check(self.lib.siggan_bind(h, C.byref(st)))
+        self.d_chans = list(layout.D_CHAIN[image_size])
+
+    # ---- views -------------------------------------------------------------------------------
+    def views(self, which, arena="params"):
+        """OrderedDict state_dict key -> view into the chosen flat arena ('params', 'grads',
+        'exp_avg', 'exp_avg_sq')."""
+        spans = self.g_spans if which == "g" else self.d_spans
+        flat = getattr(self, f"{which}_{arena}")
+        return {k: flat[o:o + n].view(shape) for k, (o, n, shape) in spans.items()}
+
+    def bn_views(self):
+        out = {}
+        for i, (k, (o, n, shape)) in enumerate(self.bn_spans.items()):
+            out[k] = self.g_bn_mean[o:o + n]
+            out[k.replace("running_mean", "running_var")] = self.g_bn_var[o:o + n]
+            out[k.replace("running_mean", "num_batches_tracked")] = self.g_bn_batches[i]
+        return out
+
+    def params_changed(self):
+        """Call after writing parameters / BN buffers from outside (load_state_dict, init)."""
+        _lib.check(self.lib.siggan_params_changed(self._h))
+
+    def seed(self, seed, offset=0):
+        _lib.check(self.lib.siggan_seed(self._h, int(seed), int(offset)))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _hyper(self, lr, beta1, beta2, eps=1e-8, label_smoothing=0.9, clip=None, grad_scale=1.0):
+        return _lib.Hyper(lr, beta1, beta2, eps, label_smoothing, clip if clip else 0.0, grad_scale)
+
+    def _check_batch(self, b):
+        if not 1 <= b <= self.max_batch:
+            raise ValueError(f"batch {b} outside [1, max_batch={self.max_batch}]")
+
+    # ---- forward passes ------------------------------------------------------------------------
+    def g_forward(self, z, training=False, out=None):
+        z = _f32(z, self.device, "z")
+        if z.dim() != 2 or z.shape[1] != self.latent_dim:
+            raise ValueError(f"z must be (B, {self.latent_dim}), got {tuple(z.shape)}")
+        b = z.shape[0]
+        self._check_batch(b)
+        if out is None:
+            out = torch.empty(b, 1, self.image_size, self.image_size, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.siggan_g_forward(self._h, _ptr(z), b, int(training), _ptr(out), self._stream()))
+        return out
+
+    def _masks(self, masks, b, passes):
+        if masks is None:
+            return None
+        if isinstance(masks, (list, tuple)):
+            assert len(masks) == passes * len(self.d_chans)
+            masks = torch.cat([m.to(self.device, torch.float32).reshape(-1) for m in masks])
+        masks = _f32(masks, self.device, "masks")
+        if masks.numel() != passes * b * sum(self.d_chans):
+            raise ValueError("dropout masks have the wrong size")
+        return masks
+
+    def d_forward(self, x, training=False, masks=None, want_features=False):
+        x = _f32(x, self.device, "x")
+        s = self.image_size
+        if x.dim() != 4 or tuple(x.shape[1:]) != (1, s, s):
+            raise ValueError(f"x must be (B, 1, {s}, {s}), got {tuple(x.shape)}")
+        b = x.shape[0]
+        self._check_batch(b)
+        masks = self._masks(masks, b, 1)
+        probs = torch.empty(b, 1, dtype=torch.float32, device=self.device)
+        feat = torch.empty(b, self.d_chans[-1] * 16, dtype=torch.float32, device=self.device) if want_features else None
+        _lib.check(self.lib.siggan_d_forward(self._h, _ptr(x), b, int(training), _ptr(masks), _ptr(probs), _ptr(feat),
+                                             self._stream()))
+        return (probs, feat) if want_features else probs
+
+    # ---- training steps --------------------------------------------------------------------------
+    def _metrics(self, keys, sync):
+        if not sync:
+            return None
+        host = self.metrics.cpu()
+        return {k: float(host[_lib.METRIC_INDEX[k]]) for k in keys}
+
+    D_KEYS = ("d_loss", "d_loss_real", "d_loss_fake", "d_real_mean", "d_fake_mean", "d_real_acc", "d_fake_acc")
+    G_KEYS = ("g_loss", "g_fake_mean")
+
+    def d_compute_grads(self, real, z=None, masks=None, label_smoothing=0.9):
+        real = _f32(real, self.device, "real_images")
+        s = self.image_size
+        if real.dim() != 4 or tuple(real.shape[1:]) != (1, s, s):
+            raise ValueError(f"real_images must be (B, 1, {s}, {s}), got {tuple(real.shape)}")
+        b = real.shape[0]
+        self._check_batch(b)
+        z = _f32(z, self.device, "noise")
+        if z is not None and tuple(z.shape) != (b, self.latent_dim):
+            raise ValueError(f"noise must be ({b}, {self.latent_dim})")
+        masks = self._masks(masks, b, 2)
+        hp = self._hyper(0.0, 0.5, 0.999, label_smoothing=label_smoothing)
+        _lib.check(self.lib.siggan_d_grads(self._h, _ptr(real), b, _ptr(z), _ptr(masks), C.byref(hp), _ptr(self.metrics),
+                                           self._stream()))
+
+    def d_apply(self, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8, clip=None, grad_scale=1.0, sync=True):
+        hp = self._hyper(lr, beta1, beta2, eps, clip=clip, grad_scale=grad_scale)
+        _lib.check(self.lib.siggan_d_apply(self._h, C.byref(hp), _ptr(self.metrics), None, self._stream()))
+        m = self._metrics(self.D_KEYS + (("d_grad_norm",) if clip else ()), sync)
+        if m is not None and not clip:
+            m["d_grad_norm"] = None
+        return m
+
+    def d_step(self, real, z=None, masks=None, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8, label_smoothing=0.9,
+               clip=None, sync=True):
+        self.d_compute_grads(real, z, masks, label_smoothing)
+        return self.d_apply(lr, beta1, beta2, eps, clip, 1.0, sync)
+
+    def g_compute_grads(self, batch, z=None):
+        self._check_batch(batch)
+        z = _f32(z, self.device, "noise")
+        if z is not None and tuple(z.shape) != (batch, self.latent_dim):
+            raise ValueError(f"noise must be ({batch}, {self.latent_dim})")
+        hp = self._hyper(0.0, 0.5, 0.999)
+        _lib.check(self.lib.siggan_g_grads(self._h, batch, _ptr(z), C.byref(hp), _ptr(self.metrics), self._stream()))
+
+    def g_apply(self, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8, clip=None, grad_scale=1.0, sync=True):
+        hp = self._hyper(lr, beta1, beta2, eps, clip=clip, grad_scale=grad_scale)
+        _lib.check(self.lib.siggan_g_apply(self._h, C.byref(hp), _ptr(self.metrics), None, self._stream()))
+        m = self._metrics(self.G_KEYS + (("g_grad_norm",) if clip else ()), sync)
+        if m is not None and not clip:
+            m["g_grad_norm"] = None
+        return m
+
+    def g_step(self, batch, z=None, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8, clip=None, sync=True):
+        self.g_compute_grads(batch, z)
+        return self.g_apply(lr, beta1, beta2, eps, clip, 1.0, sync)
+
+    # ---- operator-level calls (tests / profiling) --------------------------------------------------
+    def op_conv4x4s2(self, form, x_nhwc, w):
+        b, h, _, cin = x_nhwc.shape
+        cout = w.shape[0] if form == 0 else w.shape[1]
+        ho = h // 2 if form == 0 else 2 * h
+        out = torch.empty(b, ho, ho, cout, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.siggan_op_conv4x4s2(self._h, form, _ptr(x_nhwc.contiguous()), _ptr(w.contiguous()), _ptr(out),
+                                                b, h, cin, cout, self._stream()))
+        return out
+
+    def op_wgrad(self, small_nhwc, large_nhwc):
+        b, hs, _, cs = small_nhwc.shape
+        cl = large_nhwc.shape[3]
+        dw = torch.empty(cs, cl, 4, 4, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.siggan_op_conv4x4s2_wgrad(self._h, _ptr(small_nhwc.contiguous()), _ptr(large_nhwc.contiguous()),
+                                                      _ptr(dw), b, hs, cs, cl, self._stream()))
+        return dw
+
+    def op_adam(self, p, g, m, v, step, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8, clip=None, grad_scale=1.0):
+        hp = self._hyper(lr, beta1, beta2, eps, clip=clip, grad_scale=grad_scale)
+        _lib.check(self.lib.siggan_op_adam(self._h, _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step, C.byref(hp),
+                                           self._stream()))
+
+    def op_randn(self, n):
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.siggan_op_randn(self._h, _ptr(out), n, self._stream()))
+        return out
+
+    def debug_tensor(self, name, index, shape):
+        """Copy of a workspace tensor (test hook): first prod(shape) floats, reshaped."""
+        n = 1
+        for s in shape:
+            n *= s
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.siggan_debug_tensor(self._h, name.encode(), index, _ptr(out), n, self._stream()))
+        return out.view(shape)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.siggan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
