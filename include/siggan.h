@@ -180,6 +180,15 @@ int siggan_op_adam(siggan_ctx *ctx, float *p_dev, float *g_dev, float *m_dev, fl
                    int64_t n, int32_t step, const siggan_hyper *hp, void *stream);
 /* library RNG: n standard normals / n Bernoulli(keep) keep-masks */
 int siggan_op_randn(siggan_ctx *ctx, float *out_dev, int64_t n, void *stream);
+/* measurement hook (bench.py roofline leg): while enabled, every MFMA implicit-GEMM launch is
+ * bracketed by HIP events on the stream it is launched on.  siggan_prof_read synchronises the
+ * device and returns, for kernel slot idx (0..siggan_prof_slots()-1): its name, launch count,
+ * summed device time (ms) and summed algorithmic FLOPs. */
+int siggan_prof_enable(siggan_ctx *ctx, int32_t on);
+int32_t siggan_prof_slots(void);
+int siggan_prof_read(siggan_ctx *ctx, int32_t idx, char *name, int32_t name_cap, int64_t *launches,
+                     double *ms, double *flops);
+
 /* test hook: copy the first n floats of a library-owned workspace tensor (NHWC) into out_dev:
  * "g_y"/"g_a"/"g_da" (layer 0..Lg), "d_a"/"d_dv" (block 1..Ld), "img", "dpre", "logits",
  * "probs", "dlogit".  Used by tests that localise a parity failure. */

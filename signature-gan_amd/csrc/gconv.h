@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace siggan {
 
@@ -30,6 +31,11 @@ struct GConvArgs {
     const float* shift;   // [Co]
     const float* aref;    // [B][Ho][Wo][Co] stored activation (EPI_LRELU_BWD)
     float slope;
+    // split-K scratch (optional): nsplit slabs of the whole output, summed by k_splitk_epilogue
+    float* slab;
+    int64_t slab_floats;
+    size_t slab_stride;   // filled by launch_gconv
+    const float* zeros;   // >= 16 bytes of zeros (source of out-of-image taps)
 };
 
 // slab[z][i][tap*Cl + l] = sum_{pix in split z} S[pix][i] * L[n, 2p-1+kh, 2q-1+kw][l]
@@ -41,7 +47,21 @@ struct WgradArgs {
     int lgHs, lgWs, lgCl;
     int K;                // B*Hs*Ws pixels
     int kchunk;           // pixels per split (multiple of 32)
+    const float* zeros;   // >= 16 bytes of zeros
 };
+
+// Optional per-kernel timing (bench.py's roofline leg): when a profiler is installed every MFMA
+// launch is bracketed by HIP events on its own stream and tagged with its algorithmic FLOPs.
+struct Prof {
+    struct Rec { int id; double flops; hipEvent_t e0, e1; };
+    static constexpr int NID = 8;
+    std::vector<Rec> recs;
+    static const char* name(int id);
+    void begin(int id, double flops, hipStream_t st);
+    void end(hipStream_t st);
+    void clear();
+};
+extern Prof* g_prof;
 
 void launch_gconv(const GConvArgs& a, hipStream_t st);
 // returns the number of K splits it used (slab must hold max_splits*Cs*16*Cl floats)

@@ -20,6 +20,7 @@
 namespace siggan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int BK = 32;    // K-tile (floats)
 static constexpr int PAD = 4;    // LDS row padding (floats)
@@ -35,7 +36,9 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int PA = BM / 32, PB = BN / 32;
-    constexpr int LDA = BM + PAD, LDB = BN + PAD;
+    // row stride == 1 (mod 8): the transposing ds_write_b32 of a staged float4 (8 k-chunks x 4 rows
+    // per 32-lane half) hits 32 distinct banks; fragment reads walk consecutive floats.
+    constexpr int LDA = BM + 1, LDB = BN + 1;
     __shared__ float smem[2 * BK * (LDA + LDB)];
     float* const sA = smem;
     float* const sB = smem + 2 * BK * LDA;
@@ -52,7 +55,12 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     const int ntaps = a.form == 0 ? 16 : 4;
     const int Ktot = ntaps * a.Ci;
     const int cpt = a.Ci / BK;                 // K-tiles per tap (power of two)
-    const int nk = ntaps * cpt;
+    const int nk_all = ntaps * cpt;
+    // split-K: this block owns K-tiles [k_lo, k_hi)
+    const int kper = (nk_all + gridDim.y - 1) / gridDim.y;
+    const int k_lo = blockIdx.y * kper;
+    const int k_hi = min(nk_all, k_lo + kper);
+    const int nk = k_hi - k_lo;
 
     // ---- per-thread staging coordinates -------------------------------------------------
     const int kc = tid & 7, rloc = tid >> 3;   // 8 float4 chunks per 32-float k-row
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     const float* const wbase = a.wp + ((size_t)cls * a.Co + n0 + rloc) * Ktot + kc * 4;
 
     float4 ra[PA], rb[PB];
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
         const int tap = kt / cpt, ci0 = (kt - tap * cpt) * BK;
         int dh, dw;
         if (a.form == 0) { dh = tap >> 2; dw = tap & 3; } else { dh = -(tap >> 1); dw = -(tap & 1); }
@@ -81,18 +89,16 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
         for (int p = 0; p < PA; ++p) {
             const int ih = a_ih0[p] + dh, iw = a_iw0[p] + dw;
             const bool ok = (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
-            if (ok) {
-                const size_t off = ((size_t)(a_nb[p] + ih * a.Wi + iw)) * a.Ci + ci0 + kc * 4;
-                ra[p] = *reinterpret_cast<const float4*>(a.in + off);
-            } else {
-                ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            // out-of-image taps read a 16-byte page of zeros: the select is on the ADDRESS, so the
+            // loads stay unconditional and nothing waits on their data until store_tile
+            const float* src = ok ? a.in + (((size_t)(a_nb[p] + ih * a.Wi + iw)) * a.Ci + ci0 + kc * 4) : a.zeros;
+            ra[p] = *reinterpret_cast<const float4*>(src);
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p)
             rb[p] = *reinterpret_cast<const float4*>(wbase + (size_t)(32 * p) * Ktot + kt * BK);
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
         float* dA = sA + buf * BK * LDA + (kc * 4) * LDA + rloc;
         float* dB = sB + buf * BK * LDB + (kc * 4) * LDB + rloc;
 #pragma unroll
@@ -115,33 +121,50 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    if (nk > 0) {
+        load_tile(k_lo);
+        store_tile(0);
+    }
     __syncthreads();
 
+    // Main loop, one barrier per K-tile.  Per tile: fragments are read one sub-step ahead of the
+    // MFMAs that use them (counted lgkmcnt), the next tile's global loads are issued behind the
+    // first MFMAs and written to the other LDS buffer in the middle of the tile, so that only the
+    // barrier and the first fragment read are exposed.
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        const bool more = kt + 1 < nk;
         const float* pA = sA + buf * BK * LDA + lh * LDA + wm * (32 * TM) + li;
         const float* pB = sB + buf * BK * LDB + lh * LDB + wn * (32 * TN) + li;
+        float fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = pA[32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = pB[32 * j];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            float fa[TM], fb[TN];
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = pA[(2 * s) * LDA + 32 * i];
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = pA[(2 * s + 2) * LDA + 32 * i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = pB[(2 * s) * LDB + 32 * j];
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = pB[(2 * s + 2) * LDB + 32 * j];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the next sub-step's reads ahead of these MFMAs
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+            if (s == 0 && more) load_tile(k_lo + kt + 1);
+            if (s == BK / 2 - 6 && more) store_tile(buf ^ 1);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue ----------------------------------------------------------------------
+    float* const outp = gridDim.y > 1 ? a.slab + (size_t)blockIdx.y * a.slab_stride : a.out;
+    const int epi = gridDim.y > 1 ? (int)EPI_RAW : a.epi;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -161,41 +184,125 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
                 const int co = n0 + wn * (32 * TN) + 32 * j + li;
                 float v = acc[i][j][r];
                 const size_t o = opix * a.Co + co;
-                if (a.epi == EPI_BIAS_LRELU_DROP) {
+                if (epi == EPI_BIAS_LRELU_DROP) {
                     v += a.bias[co];
                     v = v > 0.f ? v : v * a.slope;
                     if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
-                } else if (a.epi == EPI_AFFINE_RELU) {
+                } else if (epi == EPI_AFFINE_RELU) {
                     v = fmaxf(fmaf(v, a.scale[co], a.shift[co]), 0.f);
-                } else if (a.epi == EPI_LRELU_BWD) {
+                } else if (epi == EPI_LRELU_BWD) {
                     const float ar = a.aref[o];
                     v *= ar > 0.f ? 1.f : a.slope;
                     if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
                 }
-                a.out[o] = v;
+                outp[o] = v;
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-static void launch_cfg(const GConvArgs& a, hipStream_t st) {
-    const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
-    dim3 grid(tiles, 1, a.form == 0 ? 1 : 4);
-    hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+// split-K tail: out = epilogue(sum_z slab[z]) over the NHWC output (4 channels per thread)
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int nsplit, int64_t total4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const float4* sl = reinterpret_cast<const float4*>(a.slab);
+    const size_t stride4 = a.slab_stride / 4;
+    float4 v = sl[i];
+    for (int z = 1; z < nsplit; ++z) {
+        const float4 w = sl[(size_t)z * stride4 + i];
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    const int C4 = a.Co / 4;
+    const int c = (int)(i % C4) * 4;
+    const int64_t n = i / ((int64_t)C4 * a.Ho * a.Wo);
+    float* e = reinterpret_cast<float*>(&v);
+    if (a.epi == EPI_BIAS_LRELU_DROP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x = e[k] + a.bias[c + k];
+            x = x > 0.f ? x : x * a.slope;
+            if (a.noise) x *= a.noise[n * a.Co + c + k];
+            e[k] = x;
+        }
+    } else if (a.epi == EPI_AFFINE_RELU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = fmaxf(fmaf(e[k], a.scale[c + k], a.shift[c + k]), 0.f);
+    } else if (a.epi == EPI_LRELU_BWD) {
+        const float4 ar = reinterpret_cast<const float4*>(a.aref)[i];
+        const float* r = reinterpret_cast<const float*>(&ar);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x = e[k] * (r[k] > 0.f ? 1.f : a.slope);
+            if (a.noise) x *= a.noise[n * a.Co + c + k];
+            e[k] = x;
+        }
+    }
+    reinterpret_cast<float4*>(a.out)[i] = v;
 }
 
-void launch_gconv(const GConvArgs& a, hipStream_t st) {
-    // Pick the largest tile that still yields >= ~256 workgroups (one per CU); Co is a
-    // multiple of 32 and a power of two for every layer of the model.
+Prof* g_prof = nullptr;
+const char* Prof::name(int id) {
+    static const char* n[NID] = {"k_gconv<128,128>", "k_gconv<128,64>", "k_gconv<64,64>", "k_gconv<128,32>",
+                                 "k_wgrad<128,128>", "k_wgrad<64,128>", "k_wgrad<32,128>", "?"};
+    return n[id < 0 || id >= NID ? NID - 1 : id];
+}
+void Prof::begin(int id, double flops, hipStream_t st) {
+    Rec r; r.id = id; r.flops = flops;
+    (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, st);
+    recs.push_back(r);
+}
+void Prof::end(hipStream_t st) { (void)hipEventRecord(recs.back().e1, st); }
+void Prof::clear() {
+    for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    recs.clear();
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
+    const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
+    const int ncls = a.form == 0 ? 1 : 4;
+    dim3 grid(tiles, nsplit, ncls);
+    // algorithmic FLOPs = 2 * M * Co * (taps * Ci) per class (== 2 * conv MACs, padding taps included)
+    if (g_prof) g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, st);
+    hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+    if (g_prof) g_prof->end(st);
+    if (nsplit > 1) {
+        const int64_t total4 = (int64_t)a.B * a.Ho * a.Wo * a.Co / 4;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a, nsplit, total4);
+    }
+}
+
+void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
+    // Tile choice: the fp32 MFMA is slow enough that a 32x32 accumulator per wave already runs the
+    // matrix pipe at full rate, so what matters is having >= 2 workgroups per CU (512 on the chip)
+    // to cover each other's barrier / first-fragment bubbles.  Take the largest tile that still
+    // gives that; when even 64x64 tiles cannot, split K into slabs (summed by k_splitk_epilogue).
+    GConvArgs a = a_in;
     const int ncls = a.form == 0 ? 1 : 4;
     auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * (a.Co / bn) * ncls; };
+    const int nk = (a.form == 0 ? 16 : 4) * (a.Ci / BK);
+    auto splits = [&](int nblk) {
+        int ns = 1;
+        if (a.slab && nblk < 384) {
+            ns = (512 + nblk - 1) / nblk;
+            if (ns > nk / 4) ns = nk / 4;
+            if (ns > 8) ns = 8;
+            const int64_t out_floats = (int64_t)a.B * a.Ho * a.Wo * a.Co;
+            if (ns > 1 && (int64_t)ns * out_floats > a.slab_floats) ns = (int)(a.slab_floats / out_floats);
+            if (ns < 1) ns = 1;
+        }
+        a.slab_stride = (size_t)a.B * a.Ho * a.Wo * a.Co;
+        return ns;
+    };
     if (a.Co >= 64) {
-        if (a.Co >= 128 && blocks(128, 128) >= 256) return launch_cfg<128, 128, 2, 2>(a, st);
-        if (blocks(128, 64) >= 256) return launch_cfg<128, 64, 2, 2>(a, st);
-        return launch_cfg<64, 64, 2, 2>(a, st);
+        if (a.Co >= 128 && blocks(128, 128) >= 512) return launch_cfg<128, 128, 2, 2>(a, st, 0, 1);
+        if (blocks(128, 64) >= 512) return launch_cfg<128, 64, 2, 2>(a, st, 1, 1);
+        const int ns = splits(blocks(64, 64));
+        return launch_cfg<64, 64, 2, 2>(a, st, 2, ns);
     }
-    return launch_cfg<128, 32, 4, 1>(a, st);   // Co == 32
+    const int ns = splits(blocks(128, 32));
+    return launch_cfg<128, 32, 4, 1>(a, st, 3, ns);   // Co == 32
 }
 
 // ------------------------------------------------------------------------------------------
@@ -227,34 +334,32 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
     const int jj = j0 + cb * 4, tap = jj >> a.lgCl, lch = jj & (Cl - 1);
     const int kh = tap >> 2, kw = tap & 3;
 
-    float4 ra[PA], rb[PB];
-    auto load_tile = [&](int kt) {
-        const int kbase = kbeg + kt * BK;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const int pix = kbase + ka + RA * p;
-            ra[p] = pix < kend ? *reinterpret_cast<const float4*>(a.S + (size_t)pix * a.Cs + i0 + ca * 4)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int pix = kbase + kb + RB * p;
-            bool ok = pix < kend;
-            const int n = pix >> (a.lgHs + a.lgWs);
-            const int ih = 2 * ((pix >> a.lgWs) & (Hs - 1)) - 1 + kh, iw = 2 * (pix & (Ws - 1)) - 1 + kw;
-            ok = ok && (unsigned)ih < (unsigned)Hl && (unsigned)iw < (unsigned)Wl;
-            rb[p] = ok ? *reinterpret_cast<const float4*>(a.L + (((size_t)n * Hl + ih) * Wl + iw) * Cl + lch)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < PA; ++p)
-            *reinterpret_cast<float4*>(sA + buf * BK * LDA + (ka + RA * p) * LDA + ca * 4) = ra[p];
-#pragma unroll
-        for (int p = 0; p < PB; ++p)
-            *reinterpret_cast<float4*>(sB + buf * BK * LDB + (kb + RB * p) * LDB + cb * 4) = rb[p];
-    };
+    f32x4 ra[PA], rb[PB];
+    // (macros, not lambdas: hipcc left the staged float4 arrays in scratch when these were lambdas)
+#define WG_LOAD_TILE(KT)                                                                              \
+    {                                                                                                 \
+        const int kbase = kbeg + (KT) * BK;                                                           \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                              \
+            const int pix = kbase + ka + RA * p;                                                      \
+            const float* src = pix < kend ? a.S + ((size_t)pix * a.Cs + i0 + ca * 4) : a.zeros;       \
+            ra[p] = *reinterpret_cast<const f32x4*>(src);                                            \
+        }                                                                                             \
+        _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                              \
+            const int pix = kbase + kb + RB * p;                                                      \
+            const int n = pix >> (a.lgHs + a.lgWs);                                                   \
+            const int ih = 2 * ((pix >> a.lgWs) & (Hs - 1)) - 1 + kh, iw = 2 * (pix & (Ws - 1)) - 1 + kw; \
+            const bool ok = pix < kend && (unsigned)ih < (unsigned)Hl && (unsigned)iw < (unsigned)Wl; \
+            const float* src = ok ? a.L + ((((size_t)n * Hl + ih) * Wl + iw) * Cl + lch) : a.zeros;   \
+            rb[p] = *reinterpret_cast<const f32x4*>(src);                                            \
+        }                                                                                             \
+    }
+#define WG_STORE_TILE(BUF)                                                                            \
+    {                                                                                                 \
+        _Pragma("unroll") for (int p = 0; p < PA; ++p)                                                \
+            *reinterpret_cast<f32x4*>(sA + (BUF) * BK * LDA + (ka + RA * p) * LDA + ca * 4) = ra[p]; \
+        _Pragma("unroll") for (int p = 0; p < PB; ++p)                                                \
+            *reinterpret_cast<f32x4*>(sB + (BUF) * BK * LDB + (kb + RB * p) * LDB + cb * 4) = rb[p]; \
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -265,32 +370,43 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (nk > 0) {
-        load_tile(0);
-        store_tile(0);
+        WG_LOAD_TILE(0)
+        WG_STORE_TILE(0)
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        const bool more = kt + 1 < nk;
         const float* pA = sA + buf * BK * LDA + lh * LDA + wm * (32 * TM) + li;
         const float* pB = sB + buf * BK * LDB + lh * LDB + wn * (32 * TN) + li;
+        float fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = pA[32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = pB[32 * j];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            float fa[TM], fb[TN];
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = pA[(2 * s) * LDA + 32 * i];
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = pA[(2 * s + 2) * LDA + 32 * i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = pB[(2 * s) * LDB + 32 * j];
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = pB[(2 * s + 2) * LDB + 32 * j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+            if (s == 0 && more) WG_LOAD_TILE(kt + 1)
+            if (s == BK / 2 - 6 && more) WG_STORE_TILE(buf ^ 1)
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
 
+#undef WG_LOAD_TILE
+#undef WG_STORE_TILE
     float* const out = a.slab + (size_t)blockIdx.z * a.Cs * N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -317,9 +433,11 @@ int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
     a.kchunk = per * BK;
     nsplit = (ktiles + per - 1) / per;
     dim3 grid(tiles, 1, nsplit);
+    if (g_prof) g_prof->begin(bm == 128 ? 4 : bm == 64 ? 5 : 6, 2.0 * a.Cs * (double)N * a.K, st);
     if (bm == 128) hipLaunchKernelGGL((k_wgrad<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
     else if (bm == 64) hipLaunchKernelGGL((k_wgrad<64, 128, 2, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, a);
+    if (g_prof) g_prof->end(st);
     return nsplit;
 }
 

@@ -28,7 +28,8 @@ void launch_tick(DevState* st, hipStream_t s);
 
 // ---- Generator pieces ---------------------------------------------------------------------
 // y[n][f'] = z[n,:] . W[f,:] + b[f],  f' = hw*C0 + c  <->  f = c*16 + hw   (NHWC feature order)
-void launch_fc_fwd(const float* z, const float* W, const float* b, float* y, int B, int K, int C0, hipStream_t s);
+void launch_fc_pack(const float* W, float* Wt, int K, int C0, hipStream_t s);   // Wt[k][f'] = W[f][k]
+void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s);
 // dW[f][k] = sum_n dy[n][f'] z[n][k];  db[f] = sum_n dy[n][f']
 void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s);
 

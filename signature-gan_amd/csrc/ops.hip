@@ -66,76 +66,109 @@ void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, 
 void launch_tick(DevState* st, hipStream_t s) { hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, s, st); }
 
 // =========================================================================================
-// generic two-stage column reduction: grid (C/64, chunks), block = 64 columns x 4 row lanes
+// generic two-stage column reduction over an [R][C] fp32 matrix (C % 4 == 0).
+// stage 1: a 256-thread block covers cg float4 column groups x (256/cg) row lanes of one row chunk
+//          (16-byte loads, lanes walk the channel axis), LDS-combines its row lanes and writes one
+//          partial row per chunk;  stage 2 (gather2): 64 columns x 16 lanes add the chunk partials.
 // =========================================================================================
-struct ColPlan { int nch; int rows; };
+struct ColPlan { int cg, cbx, nch, rows; };
 static ColPlan col_plan(int64_t R, int C) {
-    const int cb = cdiv(C, 64);
-    int nch = 1024 / cb;
-    if (nch < 1) nch = 1;
-    const int64_t max_ch = (R + 15) / 16;
+    const int C4 = C / 4;
+    ColPlan p;
+    p.cg = C4 < 64 ? C4 : 64;              // C4 is a power of two for every layer
+    p.cbx = cdiv(C4, p.cg);
+    const int rl = 256 / p.cg;
+    int nch = 1024 / p.cbx;
+    if (nch > 256) nch = 256;
+    const int64_t max_ch = (R + 2 * rl - 1) / (2 * rl);
     if (nch > max_ch) nch = (int)max_ch;
     if (nch < 1) nch = 1;
     int rows = (int)((R + nch - 1) / nch);
-    rows = (rows + 3) & ~3;
-    nch = (int)((R + rows - 1) / rows);
-    return {nch, rows};
+    rows = ((rows + rl - 1) / rl) * rl;
+    p.nch = (int)((R + rows - 1) / rows);
+    p.rows = rows;
+    return p;
 }
 
+__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
 template <class F>
-__global__ __launch_bounds__(256) void k_colreduce(F f, int64_t R, int C, int rows, float* __restrict__ p0,
+__global__ __launch_bounds__(256) void k_colreduce(F f, int64_t R, int C, int cg, int rows, float* __restrict__ p0,
                                                    float* __restrict__ p1) {
-    __shared__ float sh[2][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float4 sh[2][256];
+    const int C4 = C / 4, rl = 256 / cg;
+    const int cl = threadIdx.x % cg, lane = threadIdx.x / cg;
+    const int c4 = blockIdx.x * cg + cl;
     const int64_t r0 = (int64_t)blockIdx.y * rows;
     const int64_t r1 = r0 + rows < R ? r0 + rows : R;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < C)
-        for (int64_t r = r0 + rl; r < r1; r += 4) f(r, c, s0, s1);
-    sh[0][rl][cl] = s0; sh[1][rl][cl] = s1;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (c4 < C4)
+        for (int64_t r = r0 + lane; r < r1; r += rl) f(r, c4, C4, s0, s1);
+    sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1;
     __syncthreads();
-    if (rl == 0 && c < C) {
-        p0[(size_t)blockIdx.y * C + c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
-        p1[(size_t)blockIdx.y * C + c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+    if (lane == 0 && c4 < C4) {
+        for (int k = 1; k < rl; ++k) { add4(s0, sh[0][k * cg + cl]); add4(s1, sh[1][k * cg + cl]); }
+        reinterpret_cast<float4*>(p0 + (size_t)blockIdx.y * C)[c4] = s0;
+        reinterpret_cast<float4*>(p1 + (size_t)blockIdx.y * C)[c4] = s1;
     }
+}
+
+// stage 2: a 1024-thread block finalizes 64 columns; 16 lanes add the chunk partials, LDS combines
+// the lanes in a fixed order (bitwise reproducible).
+__device__ __forceinline__ void gather2(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int C,
+                                        float& s, float& q, float (*sh)[16][64]) {
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, nl = blockDim.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int k = rl; k < nch; k += nl) { a += p0[(size_t)k * C + c]; if (p1) b += p1[(size_t)k * C + c]; }
+    }
+    sh[0][rl][cl] = a; sh[1][rl][cl] = b;
+    __syncthreads();
+    s = 0.f; q = 0.f;
+    for (int k = 0; k < nl; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
 }
 
 struct FSum {
-    const float* x; int C;
-    __device__ void operator()(int64_t r, int c, float& s0, float& s1) const { s0 += x[r * C + c]; }
+    const float4* x;
+    __device__ void operator()(int64_t r, int c4, int C4, float4& s0, float4& s1) const { add4(s0, x[r * C4 + c4]); }
 };
 struct FStats {   // shifted sums around the first row: robust single-pass variance
-    const float* y; int C;
-    __device__ void operator()(int64_t r, int c, float& s0, float& s1) const {
-        const float v = y[r * C + c] - y[c];
-        s0 += v; s1 += v * v;
+    const float4* y;
+    __device__ void operator()(int64_t r, int c4, int C4, float4& s0, float4& s1) const {
+        const float4 v = y[r * C4 + c4], p = y[c4];
+        const float4 d = make_float4(v.x - p.x, v.y - p.y, v.z - p.z, v.w - p.w);
+        add4(s0, d);
+        s1.x = fmaf(d.x, d.x, s1.x); s1.y = fmaf(d.y, d.y, s1.y); s1.z = fmaf(d.z, d.z, s1.z); s1.w = fmaf(d.w, d.w, s1.w);
     }
 };
 struct FBnBwd {
-    const float* da; const float* y; const float* a; const float* bn; int C;
-    __device__ void operator()(int64_t r, int c, float& s0, float& s1) const {
-        const size_t i = (size_t)r * C + c;
-        const float d = a[i] > 0.f ? da[i] : 0.f;
-        const float xh = (y[i] - bn[2 * C + c]) * bn[3 * C + c];
-        s0 += d; s1 += d * xh;
+    const float4* da; const float4* y; const float4* a; const float4* bn;
+    __device__ void operator()(int64_t r, int c4, int C4, float4& s0, float4& s1) const {
+        const size_t i = (size_t)r * C4 + c4;
+        const float4 g = da[i], yy = y[i], aa = a[i], mu = bn[2 * C4 + c4], rs = bn[3 * C4 + c4];
+        const float4 d = make_float4(aa.x > 0.f ? g.x : 0.f, aa.y > 0.f ? g.y : 0.f, aa.z > 0.f ? g.z : 0.f, aa.w > 0.f ? g.w : 0.f);
+        add4(s0, d);
+        s1.x = fmaf(d.x, (yy.x - mu.x) * rs.x, s1.x); s1.y = fmaf(d.y, (yy.y - mu.y) * rs.y, s1.y);
+        s1.z = fmaf(d.z, (yy.z - mu.z) * rs.z, s1.z); s1.w = fmaf(d.w, (yy.w - mu.w) * rs.w, s1.w);
     }
 };
 
 __device__ __forceinline__ int perm16(int c, int perm_c0) { return perm_c0 > 0 ? (c % perm_c0) * 16 + c / perm_c0 : c; }
 
-__global__ void k_colsum_fin(const float* __restrict__ p0, int nch, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < nch; ++k) s += p0[(size_t)k * C + c];
-    out[c] = s;
+__global__ __launch_bounds__(1024) void k_colsum_fin(const float* __restrict__ p0, int nch, int C, float* __restrict__ out) {
+    __shared__ float sh[2][16][64];
+    float s, q;
+    gather2(p0, nullptr, nch, C, s, q, sh);
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (threadIdx.x < 64 && c < C) out[c] = s;
 }
 void launch_colsum(const float* x, int64_t R, int C, float* out, float* partial, hipStream_t s) {
     const ColPlan pl = col_plan(R, C);
     float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
-    hipLaunchKernelGGL((k_colreduce<FSum>), dim3(cdiv(C, 64), pl.nch), dim3(256), 0, s, FSum{x, C}, R, C, pl.rows, p0, p1);
-    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(C, 256)), dim3(256), 0, s, p0, pl.nch, C, out);
+    hipLaunchKernelGGL((k_colreduce<FSum>), dim3(pl.cbx, pl.nch), dim3(256), 0, s, FSum{(const float4*)x}, R, C, pl.cg, pl.rows, p0, p1);
+    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, pl.nch, C, out);
 }
 
 // =========================================================================================
@@ -156,16 +189,17 @@ void launch_bn_eval_affine(const float* gamma, const float* beta, const float* r
     hipLaunchKernelGGL(k_bn_eval_affine, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, rmean, rvar, bn, C, perm_c0, eps);
 }
 
-__global__ void k_bn_train_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
+__global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
                                const float* __restrict__ y, const float* __restrict__ gamma,
                                const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                int64_t* __restrict__ batches, float* __restrict__ bn, int perm_c0, float momentum,
                                float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && batches) batches[0] += 1;
-    if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int k = 0; k < nch; ++k) { s += p0[(size_t)k * C + c]; q += p1[(size_t)k * C + c]; }
+    __shared__ float sh[2][16][64];
+    float s, q;
+    gather2(p0, p1, nch, C, s, q, sh);
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && batches) batches[0] += 1;
+    if (threadIdx.x >= 64 || c >= C) return;
     const float invR = 1.0f / (float)R;
     const float d = s * invR;
     const float mean = y[c] + d;
@@ -184,8 +218,8 @@ void launch_bn_train_stats(const float* y, int64_t R, int C, const float* gamma,
                            float eps, hipStream_t s) {
     const ColPlan pl = col_plan(R, C);
     float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
-    hipLaunchKernelGGL((k_colreduce<FStats>), dim3(cdiv(C, 64), pl.nch), dim3(256), 0, s, FStats{y, C}, R, C, pl.rows, p0, p1);
-    hipLaunchKernelGGL(k_bn_train_fin, dim3(cdiv(C, 256)), dim3(256), 0, s, p0, p1, pl.nch, R, C, y, gamma, beta, rmean,
+    hipLaunchKernelGGL((k_colreduce<FStats>), dim3(pl.cbx, pl.nch), dim3(256), 0, s, FStats{(const float4*)y}, R, C, pl.cg, pl.rows, p0, p1);
+    hipLaunchKernelGGL(k_bn_train_fin, dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, p1, pl.nch, R, C, y, gamma, beta, rmean,
                        rvar, batches, bn, perm_c0, momentum, eps);
 }
 
@@ -204,12 +238,13 @@ void launch_bn_relu(const float* y, float* a, int64_t R, int C, const float* bn,
                        (const float4*)bn);
 }
 
-__global__ void k_bn_bwd_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
+__global__ __launch_bounds__(1024) void k_bn_bwd_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
                              float* __restrict__ bn, float* __restrict__ dgamma, float* __restrict__ dbeta, int perm_c0) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int k = 0; k < nch; ++k) { s += p0[(size_t)k * C + c]; q += p1[(size_t)k * C + c]; }
+    __shared__ float sh[2][16][64];
+    float s, q;
+    gather2(p0, p1, nch, C, s, q, sh);
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (threadIdx.x >= 64 || c >= C) return;
     const int t = perm16(c, perm_c0);
     dbeta[t] = s; dgamma[t] = q;
     const float invR = 1.0f / (float)R;
@@ -233,9 +268,9 @@ void launch_bn_bwd(float* da, const float* y, const float* a, int64_t R, int C, 
                    float* dgamma, float* dbeta, int perm_c0, hipStream_t s) {
     const ColPlan pl = col_plan(R, C);
     float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
-    hipLaunchKernelGGL((k_colreduce<FBnBwd>), dim3(cdiv(C, 64), pl.nch), dim3(256), 0, s, FBnBwd{da, y, a, bn, C}, R, C,
-                       pl.rows, p0, p1);
-    hipLaunchKernelGGL(k_bn_bwd_fin, dim3(cdiv(C, 256)), dim3(256), 0, s, p0, p1, pl.nch, R, C, bn, dgamma, dbeta, perm_c0);
+    hipLaunchKernelGGL((k_colreduce<FBnBwd>), dim3(pl.cbx, pl.nch), dim3(256), 0, s,
+                       FBnBwd{(const float4*)da, (const float4*)y, (const float4*)a, (const float4*)bn}, R, C, pl.cg, pl.rows, p0, p1);
+    hipLaunchKernelGGL(k_bn_bwd_fin, dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, p1, pl.nch, R, C, bn, dgamma, dbeta, perm_c0);
     const int64_t n4 = R * C / 4;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, s, (float4*)da, (const float4*)y,
                        (const float4*)a, n4, C / 4, (const float4*)bn);
@@ -244,20 +279,44 @@ void launch_bn_bwd(float* da, const float* y, const float* a, int64_t R, int C, 
 // =========================================================================================
 // Generator fc (latent x weight) -- K = latent_dim is tiny; one thread per output
 // =========================================================================================
-__global__ void k_fc_fwd(const float* __restrict__ z, const float* __restrict__ W, const float* __restrict__ b,
-                         float* __restrict__ y, int B, int K, int C0) {
+// Wt[k][f'] = W[f][k]: k-major copy in the NHWC feature order, so lanes walk f' (coalesced)
+__global__ void k_fc_pack(const float* __restrict__ W, float* __restrict__ Wt, int K, int C0) {
     const int F = C0 * 16;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)B * F) return;
-    const int fp = (int)(idx % F), n = (int)(idx / F);
-    const int f = (fp % C0) * 16 + fp / C0;
-    const float* zr = z + (size_t)n * K; const float* wr = W + (size_t)f * K;
-    float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc = fmaf(zr[k], wr[k], acc);
-    y[idx] = acc + b[f];
+    if (idx >= (int64_t)K * F) return;
+    const int fp = (int)(idx % F), k = (int)(idx / F);
+    Wt[idx] = W[(size_t)((fp % C0) * 16 + fp / C0) * K + k];
 }
-void launch_fc_fwd(const float* z, const float* W, const float* b, float* y, int B, int K, int C0, hipStream_t s) {
-    hipLaunchKernelGGL(k_fc_fwd, dim3(cdiv((int64_t)B * C0 * 16, 256)), dim3(256), 0, s, z, W, b, y, B, K, C0);
+void launch_fc_pack(const float* W, float* Wt, int K, int C0, hipStream_t s) {
+    hipLaunchKernelGGL(k_fc_pack, dim3(cdiv((int64_t)K * C0 * 16, 256)), dim3(256), 0, s, W, Wt, K, C0);
+}
+// one thread = one feature f' x 8 batch rows; z rows broadcast from LDS
+__global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, const float* __restrict__ Wt,
+                                                const float* __restrict__ b, float* __restrict__ y, int B, int K, int C0) {
+    extern __shared__ float sz[];   // [8][K]
+    const int F = C0 * 16;
+    const int fp = blockIdx.x * 256 + threadIdx.x, nb = blockIdx.y * 8;
+    for (int i = threadIdx.x; i < 8 * K; i += 256) {
+        const int n = nb + i / K;
+        sz[i] = n < B ? z[(size_t)n * K + i % K] : 0.f;
+    }
+    __syncthreads();
+    if (fp >= F) return;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float w = Wt[(size_t)k * F + fp];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(sz[j * K + k], w, acc[j]);
+    }
+    const float bias = b[(fp % C0) * 16 + fp / C0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (nb + j < B) y[(size_t)(nb + j) * F + fp] = acc[j] + bias;
+}
+void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s) {
+    hipLaunchKernelGGL(k_fc_fwd, dim3(cdiv(C0 * 16, 256), cdiv(B, 8)), dim3(256), 8 * K * sizeof(float), s, z, Wt, b, y, B, K, C0);
 }
 __global__ void k_fc_wgrad(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dW,
                            float* __restrict__ db, int B, int K, int C0) {
@@ -387,24 +446,25 @@ __global__ __launch_bounds__(256) void k_final_wgrad(const float* __restrict__ d
         out[o] = s;
     }
 }
-__global__ void k_rows_sum(const float* __restrict__ partial, int nch, int width, float* __restrict__ o0, int n0,
+__global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ partial, int nch, int width, float* __restrict__ o0, int n0,
                            float* __restrict__ o1) {
     // out[j] = sum_k partial[k][j];  j < n0 -> o0[j], else o1[j - n0]
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= width) return;
-    float s = 0.f;
-    for (int k = 0; k < nch; ++k) s += partial[(size_t)k * width + j];
+    __shared__ float sh[2][16][64];
+    float s, q;
+    gather2(partial, nullptr, nch, width, s, q, sh);
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (threadIdx.x >= 64 || j >= width) return;
     if (j < n0) o0[j] = s; else o1[j - n0] = s;
 }
 void launch_final_wgrad(const float* dpre, const float* act, float* dW, float* db, float* partial, int B, int S, int C,
                         hipStream_t s) {
     const int64_t total = (int64_t)B * S * S;
-    int nch = 512;
+    int nch = 1024;
     int ppb = cdiv(total, nch);
     ppb = ((ppb + 7) / 8) * 8;
     nch = cdiv(total, ppb);
     hipLaunchKernelGGL(k_final_wgrad, dim3(nch), dim3(256), 0, s, dpre, act, partial, B, S, C, ppb);
-    hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 256)), dim3(256), 0, s, partial, nch, C * 9 + 1, dW, C * 9, db);
+    hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 64)), dim3(1024), 0, s, partial, nch, C * 9 + 1, dW, C * 9, db);
 }
 
 // =========================================================================================
@@ -500,12 +560,12 @@ __global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ d
 void launch_conv1_wgrad(const float* dv, const float* x0, int n0, const float* x1, float* dW, float* db, float* partial,
                         int B, int S, int C, hipStream_t s) {
     const int64_t total = (int64_t)B * (S / 2) * (S / 2);
-    int nch = 1024;
+    int nch = 512;
     int ppb = cdiv(total, nch);
     ppb = ((ppb + 3) / 4) * 4;
     nch = cdiv(total, ppb);
     hipLaunchKernelGGL(k_conv1_wgrad, dim3(nch), dim3(256), 256 * 17 * sizeof(float), s, dv, x0, n0, x1, partial, B, S, C, ppb);
-    hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 17, 256)), dim3(256), 0, s, partial, nch, C * 17, dW, C * 16, db);
+    hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 17, 64)), dim3(1024), 0, s, partial, nch, C * 17, dW, C * 16, db);
 }
 
 // 16 lanes per image pixel, 4 channels each; dpre = dimg * (1 - img^2)

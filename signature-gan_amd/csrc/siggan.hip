@@ -61,7 +61,7 @@ struct siggan_ctx {
     float *d_a[MAXL + 1], *d_dv[MAXL + 1], *d_noise[MAXL + 1];
     float *logits, *probs, *dlogit;
     float *g_up[MAXL + 1], *g_dn[MAXL + 1], *d_dn[MAXL + 1], *d_up[MAXL + 1], *wcp;
-    float *slab, *partial, *metrics, *op_pack;
+    float *slab, *partial, *metrics, *op_pack, *zeros, *wfc_t;
     int64_t slab_floats;
     DevState* dev;
     // last *_grads call (for *_apply)
@@ -182,6 +182,8 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->partial, (int64_t)2 << 20);
         carve(&c->metrics, SIGGAN_M_COUNT);
         carve(&c->op_pack, (int64_t)512 * 512 * 16);
+        carve(&c->zeros, 64);
+        carve(&c->wfc_t, (int64_t)c->F * c->latent);
         float* devp = nullptr;
         carve(&devp, 64);
         if (pass == 1) c->dev = (DevState*)devp;
@@ -264,6 +266,7 @@ static int check_call(siggan_ctx* c, int batch, bool need_bound = true) {
 
 static void repack(siggan_ctx* c, hipStream_t s) {
     if (c->g_dirty) {
+        launch_fc_pack(GP(c, gi_fc_w()), c->wfc_t, c->latent, c->gC[0], s);
         for (int l = 1; l <= c->Lg; ++l) {
             const float* w = GP(c, gi_up_w(l));                       // (Cin, Cout, 4, 4)
             launch_pack_up(w, c->g_up[l], c->gC[l - 1], c->gC[l], s);   // forward: contract Cin
@@ -286,7 +289,7 @@ static void repack(siggan_ctx* c, hipStream_t s) {
 // update) and raw pre-BN outputs kept for the backward pass; eval: BN folded into the epilogue.
 static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s) {
     const float* rm = c->st.g_bn_running_mean; const float* rv = c->st.g_bn_running_var;
-    launch_fc_fwd(z, GP(c, gi_fc_w()), GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s);
+    launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s);
     if (training)
         launch_bn_train_stats(c->fc_y, B, c->F, GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), c->st.g_bn_running_mean,
                               c->st.g_bn_running_var, c->st.g_bn_batches, c->g_bn[0], c->partial, c->gC[0], BN_MOMENTUM,
@@ -296,7 +299,7 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
     launch_bn_relu(c->fc_y, c->g_a[0], B, c->F, c->g_bn[0], s);
     for (int l = 1; l <= c->Lg; ++l) {
         const int Hi = 4 << (l - 1), Ci = c->gC[l - 1], Co = c->gC[l];
-        GConvArgs a; memset(&a, 0, sizeof a);
+        GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
         a.in = c->g_a[l - 1]; a.wp = c->g_up[l]; a.B = B; a.Hi = Hi; a.Wi = Hi; a.Ci = Ci; a.Co = Co;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = 2 * Hi; a.Wo = 2 * Hi; a.form = 1; a.M = B * Hi * Hi;
         const int C = Co;
@@ -325,7 +328,7 @@ static void d_forward_pass(siggan_ctx* c, const float* x0, int n0, const float* 
                      c->S, c->dC[1], s);
     for (int l = 2; l <= c->Ld; ++l) {
         const int Hi = c->S >> (l - 1), Ho = Hi / 2;
-        GConvArgs a; memset(&a, 0, sizeof a);
+        GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
         a.in = c->d_a[l - 1]; a.wp = c->d_dn[l]; a.out = c->d_a[l];
         a.B = Bd; a.Hi = Hi; a.Wi = Hi; a.Ci = c->dC[l - 1]; a.Co = c->dC[l];
         a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Ho; a.Wo = Ho; a.form = 0; a.M = Bd * Ho * Ho;
@@ -346,7 +349,7 @@ static void d_backward_pass(siggan_ctx* c, const float* x0, int n0, const float*
     for (int l = L; l >= 2; --l) {
         const int Ho = c->S >> l, Hi = 2 * Ho, Co = c->dC[l], Ci = c->dC[l - 1];
         if (want_wgrad) {
-            WgradArgs w; memset(&w, 0, sizeof w);
+            WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
             w.S = c->d_dv[l]; w.L = c->d_a[l - 1]; w.slab = c->slab; w.B = Bd; w.Cs = Co; w.Cl = Ci;
             w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
             const int max_splits = (int)(c->slab_floats / ((int64_t)Co * 16 * Ci));
@@ -355,7 +358,7 @@ static void d_backward_pass(siggan_ctx* c, const float* x0, int n0, const float*
             launch_colsum(c->d_dv[l], (int64_t)Bd * Ho * Ho, Co, DG(c, di_b(l)), c->partial, s);
         }
         // input gradient ("up" form): contract Cout, produce Cin at (Hi x Hi); fused leaky'/dropout of block l-1
-        GConvArgs a; memset(&a, 0, sizeof a);
+        GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
         a.in = c->d_dv[l]; a.wp = c->d_up[l]; a.out = c->d_dv[l - 1];
         a.B = Bd; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
         a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 1; a.M = Bd * Ho * Ho;
@@ -378,14 +381,14 @@ static void g_backward_pass(siggan_ctx* c, const float* z, int B, hipStream_t s)
         const int64_t R = (int64_t)B * Ho * Ho;
         launch_bn_bwd(c->g_da[l], c->g_y[l], c->g_a[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, s);
         // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
-        WgradArgs w; memset(&w, 0, sizeof w);
+        WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
         w.S = c->g_a[l - 1]; w.L = c->g_da[l]; w.slab = c->slab; w.B = B; w.Cs = Ci; w.Cl = Co;
         w.lgHs = ilog2i(Hi); w.lgWs = w.lgHs; w.lgCl = ilog2i(Co); w.K = B * Hi * Hi;
         const int max_splits = (int)(c->slab_floats / ((int64_t)Ci * 16 * Co));
         const int ns = launch_wgrad(w, max_splits, s);
         launch_wgrad_reduce(c->slab, GG(c, gi_up_w(l)), ns, Ci, Co, s);
         // input gradient ("down" form): out = Cin at Hi, contract Cout over 16 taps
-        GConvArgs a; memset(&a, 0, sizeof a);
+        GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
         a.in = c->g_da[l]; a.wp = c->g_dn[l]; a.out = c->g_da[l - 1];
         a.B = B; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
@@ -583,7 +586,7 @@ extern "C" int siggan_op_conv4x4s2(siggan_ctx* c, int32_t form, const float* in_
     if (form == 0 && h_in < 2) return fail(SIGGAN_E_INVALID, "down form needs h_in >= 2");
     HIPCHK(hipSetDevice(c->cfg.device));
     hipStream_t s = (hipStream_t)stream;
-    GConvArgs a; memset(&a, 0, sizeof a);
+    GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
     a.in = in_dev; a.wp = c->op_pack; a.out = out_dev; a.B = batch; a.Hi = h_in; a.Wi = h_in; a.Ci = c_in; a.Co = c_out;
     a.form = form; a.epi = EPI_RAW;
     if (form == 0) {
@@ -607,7 +610,7 @@ extern "C" int siggan_op_conv4x4s2_wgrad(siggan_ctx* c, const float* small_dev, 
         return fail(SIGGAN_E_INVALID, "shape not in the model family (pow2 dims, 32 <= C <= 512)");
     HIPCHK(hipSetDevice(c->cfg.device));
     hipStream_t s = (hipStream_t)stream;
-    WgradArgs w; memset(&w, 0, sizeof w);
+    WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
     w.S = small_dev; w.L = large_dev; w.slab = c->slab; w.B = batch; w.Cs = c_small; w.Cl = c_large;
     w.lgHs = w.lgWs = ilog2i(h_small); w.lgCl = ilog2i(c_large); w.K = batch * h_small * h_small;
     const int max_splits = (int)(c->slab_floats / ((int64_t)c_small * 16 * c_large));
@@ -635,6 +638,32 @@ extern "C" int siggan_op_adam(siggan_ctx* c, float* p, float* g, float* m, float
     launch_adam_prepare(c->dev, steps, 1, hp->lr, hp->beta1, hp->beta2, gs, hp->clip_max_norm, nullptr, s);
     launch_adam(p, g, m, v, n, c->dev, hp->beta1, hp->beta2, hp->eps, (clip || gs != 1.0f) ? 1 : 0, s);
     LAUNCHCHK();
+    return SIGGAN_OK;
+}
+
+static Prof g_prof_store;
+extern "C" int siggan_prof_enable(siggan_ctx* c, int32_t on) {
+    if (!c) return fail(SIGGAN_E_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    g_prof_store.clear();
+    g_prof = on ? &g_prof_store : nullptr;
+    return SIGGAN_OK;
+}
+extern "C" int32_t siggan_prof_slots(void) { return Prof::NID - 1; }
+extern "C" int siggan_prof_read(siggan_ctx* c, int32_t idx, char* name, int32_t name_cap, int64_t* launches, double* ms,
+                                double* flops) {
+    if (!c || !name || !launches || !ms || !flops || idx < 0 || idx >= Prof::NID - 1) return fail(SIGGAN_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    snprintf(name, name_cap, "%s", Prof::name(idx));
+    *launches = 0; *ms = 0.0; *flops = 0.0;
+    for (auto& r : g_prof_store.recs) {
+        if (r.id != idx) continue;
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, r.e0, r.e1));
+        *launches += 1; *ms += t; *flops += r.flops;
+    }
     return SIGGAN_OK;
 }
 

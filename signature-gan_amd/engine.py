@@ -91,6 +91,24 @@ class Engine:
             out[k.replace("running_mean", "num_batches_tracked")] = self.g_bn_batches[i]
         return out
 
+    def init_reference(self, seed=0):
+        """Fresh parameters drawn from the reference's init distribution (Conv/ConvT/Linear weight
+        ~ N(0, 0.02), biases 0, BatchNorm weight ~ N(1, 0.02), bias 0: generator_vanilla_gan.py:168-187,
+        discriminator_vanilla_gan.py:212-239); BN buffers reset; Adam state cleared.  Statistical,
+        not bit-identical to torch's own init stream."""
+        gen = torch.Generator().manual_seed(int(seed))
+        for which in ("g", "d"):
+            for k, v in self.views(which).items():
+                if k.endswith("bias"):
+                    v.zero_()
+                else:
+                    mean = 1.0 if ".1.weight" in k else 0.0
+                    v.copy_(torch.empty(v.shape).normal_(mean, 0.02, generator=gen))
+            for a in ("grads", "exp_avg", "exp_avg_sq", "adam_steps"):
+                getattr(self, f"{which}_{a}").zero_()
+        self.g_bn_mean.zero_(); self.g_bn_var.fill_(1.0); self.g_bn_batches.zero_()
+        self.params_changed()
+
     def params_changed(self):
         """Call after writing parameters / BN buffers from outside (load_state_dict, init)."""
         _lib.check(self.lib.siggan_params_changed(self._h))
@@ -229,6 +247,20 @@ class Engine:
     def op_randn(self, n):
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.siggan_op_randn(self._h, _ptr(out), n, self._stream()))
+        return out
+
+    def prof_enable(self, on=True):
+        _lib.check(self.lib.siggan_prof_enable(self._h, int(on)))
+
+    def prof_read(self):
+        """[{name, launches, ms, flops}] for every MFMA kernel slot with launches (synchronises)."""
+        out = []
+        for i in range(self.lib.siggan_prof_slots()):
+            name = C.create_string_buffer(64)
+            n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+            _lib.check(self.lib.siggan_prof_read(self._h, i, name, 64, C.byref(n), C.byref(ms), C.byref(fl)))
+            if n.value:
+                out.append({"name": name.value.decode(), "launches": n.value, "ms": ms.value, "flops": fl.value})
         return out
 
     def debug_tensor(self, name, index, shape):
