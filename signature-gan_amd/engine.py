@@ -41,13 +41,10 @@ class Engine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = _lib.load()
         self.latent_dim, self.image_size, self.max_batch = int(latent_dim), int(image_size), int(max_batch)
-        self.dropout = float(dropout)
-        cfg = _lib.Config(self.device.index, self.latent_dim, self.image_size, image_channels, self.max_batch,
-                          dropout, leaky_slope, seed)
-        h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.siggan_create(C.byref(cfg), C.byref(h)))
-        self._h = h
+        self.dropout, self.leaky_slope, self._seed = float(dropout), float(leaky_slope), int(seed)
+        self._h = None
+        self._create_context()
+        h = self._h
         self.g_entries = layout.generator_entries(latent_dim, image_size)
         self.d_entries = layout.discriminator_entries(image_size)
         self.g_spans, g_total = layout.spans(self.g_entries)
@@ -68,12 +65,34 @@ class Engine:
         self.g_bn_mean, self.g_bn_var = z(bn_total), torch.ones(bn_total, dtype=torch.float32, device=dev)
         self.g_bn_batches = z(len(self.bn_spans), torch.int64)
         self.metrics = z(_lib.M_COUNT)
+        self._bind()
+        self.d_chans = list(layout.D_CHAIN[image_size])
+
+    def _create_context(self):
+        cfg = _lib.Config(self.device.index, self.latent_dim, self.image_size, 1, self.max_batch,
+                          self.dropout, self.leaky_slope, self._seed)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.siggan_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    def _bind(self):
         st = _lib.Storage(*[t.data_ptr() for t in (
             self.g_params, self.g_grads, self.g_exp_avg, self.g_exp_avg_sq, self.g_adam_steps, self.g_bn_mean,
             self.g_bn_var, self.g_bn_batches, self.d_params, self.d_grads, self.d_exp_avg, self.d_exp_avg_sq,
             self.d_adam_steps)])
-        _lib.check(self.lib.siggan_bind(h, C.byref(st)))
-        self.d_chans = list(layout.D_CHAIN[image_size])
+        _lib.check(self.lib.siggan_bind(self._h, C.byref(st)))
+
+    def ensure_batch(self, batch):
+        """Grow the library workspace (a new context bound to the SAME arenas) when a larger batch
+        than ``max_batch`` arrives; parameters, moments and buffers are untouched."""
+        if batch <= self.max_batch:
+            return
+        torch.cuda.synchronize(self.device)
+        self.lib.siggan_destroy(self._h)
+        self.max_batch = 1 << (int(batch) - 1).bit_length()
+        self._create_context()
+        self._bind()
 
     # ---- views -------------------------------------------------------------------------------
     def views(self, which, arena="params"):
@@ -123,8 +142,9 @@ class Engine:
         return _lib.Hyper(lr, beta1, beta2, eps, label_smoothing, clip if clip else 0.0, grad_scale)
 
     def _check_batch(self, b):
-        if not 1 <= b <= self.max_batch:
-            raise ValueError(f"batch {b} outside [1, max_batch={self.max_batch}]")
+        if b < 1:
+            raise ValueError(f"batch must be >= 1, got {b}")
+        self.ensure_batch(b)
 
     # ---- forward passes ------------------------------------------------------------------------
     def g_forward(self, z, training=False, out=None):
