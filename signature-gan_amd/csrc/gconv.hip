@@ -36,12 +36,15 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int PA = BM / 32, PB = BN / 32;
-    // row stride == 1 (mod 8): the transposing ds_write_b32 of a staged float4 (8 k-chunks x 4 rows
-    // per 32-lane half) hits 32 distinct banks; fragment reads walk consecutive floats.
-    constexpr int LDA = BM + 1, LDB = BN + 1;
-    __shared__ float smem[2 * BK * (LDA + LDB)];
+    // LDS tiles are [row][k] with a row stride of 36 floats (= 4 * odd): a staged float4 is ONE
+    // ds_write_b128 (8 lanes cover a row's 128 B), and a lane's MFMA operands for 4 consecutive
+    // sub-steps are ONE conflict-free ds_read_b128 (the 16 lanes of a b128 group hit 16 distinct
+    // 16-byte slots because rows differ by 9 slots).  K is consumed in the permuted pairing
+    // k = 8c + 4*(lane>>5) + t, identical for A and B, so only the fp32 summation order changes.
+    constexpr int LD = BK + 4;
+    __shared__ __attribute__((aligned(16))) float smem[2 * LD * (BM + BN)];
     float* const sA = smem;
-    float* const sB = smem + 2 * BK * LDA;
+    float* const sB = smem + 2 * LD * BM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -54,63 +57,69 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     const int Hr = 1 << a.lgHr, Wr = 1 << a.lgWr;
     const int ntaps = a.form == 0 ? 16 : 4;
     const int Ktot = ntaps * a.Ci;
-    const int cpt = a.Ci / BK;                 // K-tiles per tap (power of two)
-    const int nk_all = ntaps * cpt;
+    const int lgcpt = 31 - __builtin_clz(a.Ci / BK);      // K-tiles per tap = Ci / 32, a power of two
+    const int nk_all = ntaps << lgcpt;
     // split-K: this block owns K-tiles [k_lo, k_hi)
     const int kper = (nk_all + gridDim.y - 1) / gridDim.y;
     const int k_lo = blockIdx.y * kper;
     const int k_hi = min(nk_all, k_lo + kper);
     const int nk = k_hi - k_lo;
 
-    // ---- per-thread staging coordinates -------------------------------------------------
-    const int kc = tid & 7, rloc = tid >> 3;   // 8 float4 chunks per 32-float k-row
-    int a_nb[PA], a_ih0[PA], a_iw0[PA];
+    // ---- per-thread staging coordinates: row rloc + 32p, 16-byte chunk kc of the 32-float k-row ------
+    const int kc = tid & 7, rloc = tid >> 3;
+    const float* a_base[PA];     // &in[n, 0, 0, kc*4] of the row's image
+    int a_ih0[PA], a_iw0[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
         const int m = m0 + rloc + 32 * p;
         if (m < a.M) {
             const int n = m >> (a.lgHr + a.lgWr);
             const int rh = (m >> a.lgWr) & (Hr - 1), rw = m & (Wr - 1);
-            a_nb[p] = n * a.Hi * a.Wi;
+            a_base[p] = a.in + (size_t)n * a.Hi * a.Wi * a.Ci + kc * 4;
             if (a.form == 0) { a_ih0[p] = 2 * rh - 1; a_iw0[p] = 2 * rw - 1; }
             else             { a_ih0[p] = rh + ph;    a_iw0[p] = rw + pw; }
         } else {
-            a_nb[p] = 0; a_ih0[p] = -(1 << 20); a_iw0[p] = -(1 << 20);
+            a_base[p] = a.in; a_ih0[p] = -(1 << 20); a_iw0[p] = -(1 << 20);
         }
     }
-    const float* const wbase = a.wp + ((size_t)cls * a.Co + n0 + rloc) * Ktot + kc * 4;
+    const float* wcur = a.wp + ((size_t)cls * a.Co + n0 + rloc) * Ktot + kc * 4 + (size_t)k_lo * BK;
 
-    float4 ra[PA], rb[PB];
-    auto load_tile = [&](int kt) __attribute__((always_inline)) {
-        const int tap = kt / cpt, ci0 = (kt - tap * cpt) * BK;
+    // load cursor: walks (tap, channel chunk) in K order; per-row source pointers are rebuilt only
+    // when the tap changes, otherwise they advance by 32 floats (0 for out-of-image taps, which
+    // read a 16-byte page of zeros so that the loads stay unconditional)
+    const float* a_cur[PA];
+    int a_step[PA];
+    int l_tap = k_lo >> lgcpt, l_cc = k_lo & ((1 << lgcpt) - 1);
+    auto set_tap = [&]() __attribute__((always_inline)) {
         int dh, dw;
-        if (a.form == 0) { dh = tap >> 2; dw = tap & 3; } else { dh = -(tap >> 1); dw = -(tap & 1); }
+        if (a.form == 0) { dh = l_tap >> 2; dw = l_tap & 3; } else { dh = -(l_tap >> 1); dw = -(l_tap & 1); }
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int ih = a_ih0[p] + dh, iw = a_iw0[p] + dw;
             const bool ok = (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
-            // out-of-image taps read a 16-byte page of zeros: the select is on the ADDRESS, so the
-            // loads stay unconditional and nothing waits on their data until store_tile
-            const float* src = ok ? a.in + (((size_t)(a_nb[p] + ih * a.Wi + iw)) * a.Ci + ci0 + kc * 4) : a.zeros;
-            ra[p] = *reinterpret_cast<const float4*>(src);
+            a_cur[p] = ok ? a_base[p] + ((size_t)(ih * a.Wi + iw) * a.Ci + l_cc * BK) : a.zeros;
+            a_step[p] = ok ? BK : 0;
         }
-#pragma unroll
-        for (int p = 0; p < PB; ++p)
-            rb[p] = *reinterpret_cast<const float4*>(wbase + (size_t)(32 * p) * Ktot + kt * BK);
     };
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
-        float* dA = sA + buf * BK * LDA + (kc * 4) * LDA + rloc;
-        float* dB = sB + buf * BK * LDB + (kc * 4) * LDB + rloc;
+    f32x4 ra[PA], rb[PB];
+    auto load_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            dA[0 * LDA + 32 * p] = ra[p].x; dA[1 * LDA + 32 * p] = ra[p].y;
-            dA[2 * LDA + 32 * p] = ra[p].z; dA[3 * LDA + 32 * p] = ra[p].w;
+            ra[p] = *reinterpret_cast<const f32x4*>(a_cur[p]);
+            a_cur[p] += a_step[p];
         }
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            dB[0 * LDB + 32 * p] = rb[p].x; dB[1 * LDB + 32 * p] = rb[p].y;
-            dB[2 * LDB + 32 * p] = rb[p].z; dB[3 * LDB + 32 * p] = rb[p].w;
-        }
+        for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(wcur + (size_t)(32 * p) * Ktot);
+        wcur += BK;
+        if (++l_cc == (1 << lgcpt)) { l_cc = 0; ++l_tap; set_tap(); }
+    };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+        float* dA = sA + buf * LD * BM + rloc * LD + kc * 4;
+        float* dB = sB + buf * LD * BN + rloc * LD + kc * 4;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(dA + 32 * p * LD) = ra[p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(dB + 32 * p * LD) = rb[p];
     };
 
     f32x16 acc[TM][TN];
@@ -121,43 +130,50 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // The register set always holds the NEXT tile: it is written to the other LDS buffer right
+    // behind the first MFMAs of a tile and immediately re-loaded with the tile after that, so every
+    // global load has a full K-tile of MFMA time to land (hipcc drains vmcnt to 0 at the LDS write
+    // whatever is newer in flight, so the write sits where nothing newer is).
     if (nk > 0) {
-        load_tile(k_lo);
+        set_tap();
+        load_tile();
         store_tile(0);
+        if (nk > 1) load_tile();
     }
     __syncthreads();
 
-    // Main loop, one barrier per K-tile.  Per tile: fragments are read one sub-step ahead of the
-    // MFMAs that use them (counted lgkmcnt), the next tile's global loads are issued behind the
-    // first MFMAs and written to the other LDS buffer in the middle of the tile, so that only the
-    // barrier and the first fragment read are exposed.
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
-        const float* pA = sA + buf * BK * LDA + lh * LDA + wm * (32 * TM) + li;
-        const float* pB = sB + buf * BK * LDB + lh * LDB + wn * (32 * TN) + li;
-        float fa[2][TM], fb[2][TN];
+        const float* pA = sA + buf * LD * BM + (wm * (32 * TM) + li) * LD + 4 * lh;
+        const float* pB = sB + buf * LD * BN + (wn * (32 * TN) + li) * LD + 4 * lh;
+        f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[0][i] = pA[32 * i];
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(pA + 32 * i * LD);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = pB[32 * j];
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(pB + 32 * j * LD);
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s + 1 < BK / 2) {
+        for (int c = 0; c < BK / 8; ++c) {
+            const int cur = c & 1, nxt = cur ^ 1;
+            if (c + 1 < BK / 8) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[nxt][i] = pA[(2 * s + 2) * LDA + 32 * i];
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const f32x4*>(pA + 32 * i * LD + 8 * (c + 1));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[nxt][j] = pB[(2 * s + 2) * LDB + 32 * j];
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const f32x4*>(pB + 32 * j * LD + 8 * (c + 1));
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the next sub-step's reads ahead of these MFMAs
+            __builtin_amdgcn_sched_barrier(0);   // keep the next chunk's reads ahead of these MFMAs
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-            if (s == 0 && more) load_tile(k_lo + kt + 1);
-            if (s == BK / 2 - 6 && more) store_tile(buf ^ 1);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
+#ifndef GCONV_ABLATE_STORE
+            if (c == 0 && kt + 1 < nk) store_tile(buf ^ 1);     // tile kt+1: loaded a tile ago
+#endif
+#ifndef GCONV_ABLATE_LOAD
+            if (c == 1 && kt + 2 < nk) load_tile();             // tile kt+2: lands during this tile
+#endif
         }
         __syncthreads();
     }
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int 
 Prof* g_prof = nullptr;
 const char* Prof::name(int id) {
     static const char* n[NID] = {"k_gconv<128,128>", "k_gconv<128,64>", "k_gconv<64,64>", "k_gconv<128,32>",
-                                 "k_wgrad<128,128>", "k_wgrad<64,128>", "k_wgrad<32,128>", "?"};
+                                 "k_wgrad<64,64>", "k_wgrad<64,128>", "k_wgrad<32,128>", "?"};
     return n[id < 0 || id >= NID ? NID - 1 : id];
 }
 void Prof::begin(int id, double flops, hipStream_t st) {
@@ -372,11 +388,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
     if (nk > 0) {
         WG_LOAD_TILE(0)
         WG_STORE_TILE(0)
+        if (nk > 1) WG_LOAD_TILE(1)
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
         const float* pA = sA + buf * BK * LDA + lh * LDA + wm * (32 * TM) + li;
         const float* pB = sB + buf * BK * LDB + lh * LDB + wn * (32 * TN) + li;
         float fa[2][TM], fb[2][TN];
@@ -399,8 +415,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-            if (s == 0 && more) WG_LOAD_TILE(kt + 1)
-            if (s == BK / 2 - 6 && more) WG_STORE_TILE(buf ^ 1)
+            if (s == 0 && kt + 1 < nk) WG_STORE_TILE(buf ^ 1)
+            if (s == 1 && kt + 2 < nk) WG_LOAD_TILE(kt + 2)
         }
         __syncthreads();
     }
@@ -420,23 +436,23 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
 }
 
 int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
+    // 64x64 tiles (one 32x32 accumulator per wave keeps the fp32 MFMA pipe full): many tiles,
+    // hence few K splits and little slab traffic; Cs == 32 uses a 32x128 tile.
     const int N = 16 << a.lgCl;
-    const int bm = a.Cs >= 128 ? 128 : a.Cs;                 // Cs in {32,64,128,256,512}
-    const int tiles = (a.Cs / bm) * (N / 128);
-    // enough K splits to put ~2 workgroups on every CU, at least 2 K-tiles per split
+    const bool small = a.Cs < 64;
+    const int tiles = small ? (N / 128) : (a.Cs / 64) * (N / 64);
     int ktiles = (a.K + BK - 1) / BK;
-    int want = (512 + tiles - 1) / tiles;
-    int nsplit = want < 1 ? 1 : want;
-    if (nsplit > ktiles / 2) nsplit = ktiles / 2 > 0 ? ktiles / 2 : 1;
+    int nsplit = (512 + tiles - 1) / tiles;                  // ~2 workgroups per CU
+    if (nsplit > ktiles / 4) nsplit = ktiles / 4;            // at least 4 K-tiles per split
     if (nsplit > max_splits) nsplit = max_splits;
+    if (nsplit < 1) nsplit = 1;
     int per = (ktiles + nsplit - 1) / nsplit;
     a.kchunk = per * BK;
     nsplit = (ktiles + per - 1) / per;
     dim3 grid(tiles, 1, nsplit);
-    if (g_prof) g_prof->begin(bm == 128 ? 4 : bm == 64 ? 5 : 6, 2.0 * a.Cs * (double)N * a.K, st);
-    if (bm == 128) hipLaunchKernelGGL((k_wgrad<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
-    else if (bm == 64) hipLaunchKernelGGL((k_wgrad<64, 128, 2, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, a);
+    if (g_prof) g_prof->begin(small ? 6 : 4, 2.0 * a.Cs * (double)N * a.K, st);
+    if (small) hipLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad<64, 64, 2, 2>), grid, dim3(256), 0, st, a);
     if (g_prof) g_prof->end(st);
     return nsplit;
 }

@@ -26,6 +26,25 @@ void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uin
 void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, hipStream_t s);
 void launch_tick(DevState* st, hipStream_t s);
 
+// ---- fused "prepare" pass: every weight re-pack / BN-eval fold of one network in ONE launch -----
+enum PrepType : int { PREP_PACK_DOWN = 0, PREP_PACK_UP, PREP_FC_T, PREP_CLS, PREP_BN_EVAL };
+struct PrepJob {
+    int type, O, I, perm;        // PACK_*: (O,I) channel counts; FC_T: O=K, I=C0; CLS: O=C; BN_EVAL: O=C, perm=perm_c0
+    const float* src;            // weights (torch layout) / gamma
+    const float* src2;           // beta
+    const float* src3;           // running_mean
+    const float* src4;           // running_var
+    float* dst;
+};
+struct PrepTable {
+    static constexpr int MAXJ = 32;
+    int njobs;
+    long long prefix[MAXJ + 1];  // prefix sums of the jobs' element counts
+    PrepJob job[MAXJ];
+};
+void prep_add(PrepTable& t, const PrepJob& j, long long count);
+void launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s);
+
 // ---- Generator pieces ---------------------------------------------------------------------
 // y[n][f'] = z[n,:] . W[f,:] + b[f],  f' = hw*C0 + c  <->  f = c*16 + hw   (NHWC feature order)
 void launch_fc_pack(const float* W, float* Wt, int K, int C0, hipStream_t s);   // Wt[k][f'] = W[f][k]

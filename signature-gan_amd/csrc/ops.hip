@@ -65,6 +65,54 @@ void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, 
 }
 void launch_tick(DevState* st, hipStream_t s) { hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, s, st); }
 
+__device__ __forceinline__ int perm16(int c, int perm_c0) { return perm_c0 > 0 ? (c % perm_c0) * 16 + c / perm_c0 : c; }
+
+// =========================================================================================
+// fused prepare pass (weight packs, fc / classifier permutes, BatchNorm eval folding)
+// =========================================================================================
+void prep_add(PrepTable& t, const PrepJob& j, long long count) {
+    if (t.njobs >= PrepTable::MAXJ) return;
+    if (t.njobs == 0) t.prefix[0] = 0;
+    t.job[t.njobs] = j;
+    t.prefix[t.njobs + 1] = t.prefix[t.njobs] + count;
+    ++t.njobs;
+}
+__global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
+    const long long total = t.prefix[t.njobs];
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        int j = 0;
+        while (idx >= t.prefix[j + 1]) ++j;
+        const PrepJob& q = t.job[j];
+        const long long i = idx - t.prefix[j];
+        if (q.type == PREP_PACK_DOWN) {            // w[o][i][tap] -> dst[o][tap*I + i]
+            const int ci = (int)(i % q.I), tap = (int)((i / q.I) % 16), o = (int)(i / ((long long)q.I * 16));
+            q.dst[i] = q.src[((size_t)o * q.I + ci) * 16 + tap];
+        } else if (q.type == PREP_PACK_UP) {       // w[i][o][kh][kw] -> dst[cls][o][(th*2+tw)*I + i]
+            const int ci = (int)(i % q.I), tt = (int)((i / q.I) % 4), o = (int)((i / ((long long)q.I * 4)) % q.O);
+            const int cls = (int)(i / ((long long)q.I * 4 * q.O));
+            const int kh = 1 - (cls >> 1) + 2 * (tt >> 1), kw = 1 - (cls & 1) + 2 * (tt & 1);
+            q.dst[i] = q.src[((size_t)ci * q.O + o) * 16 + kh * 4 + kw];
+        } else if (q.type == PREP_FC_T) {          // Wt[k][f'] = W[f][k], K = q.O, C0 = q.I
+            const int F = q.I * 16, fp = (int)(i % F), k = (int)(i / F);
+            q.dst[i] = q.src[(size_t)((fp % q.I) * 16 + fp / q.I) * q.O + k];
+        } else if (q.type == PREP_CLS) {           // wcp[hw*C + c] = Wc[c*16 + hw]
+            q.dst[i] = q.src[(i % q.O) * 16 + i / q.O];
+        } else {                                   // BN eval: [scale | shift | mean | rstd]
+            const int C = q.O, c = (int)i, tix = perm16(c, q.perm);
+            const float rstd = 1.0f / sqrtf(q.src4[tix] + eps);
+            const float sc = q.src[tix] * rstd;
+            q.dst[c] = sc; q.dst[C + c] = q.src2[tix] - q.src3[tix] * sc; q.dst[2 * C + c] = q.src3[tix]; q.dst[3 * C + c] = rstd;
+        }
+    }
+}
+void launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s) {
+    if (t.njobs == 0) return;
+    long long total = t.prefix[t.njobs];
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_prepare, dim3(blocks), dim3(256), 0, s, t, bn_eps);
+}
+
 // =========================================================================================
 // generic two-stage column reduction over an [R][C] fp32 matrix (C % 4 == 0).
 // stage 1: a 256-thread block covers cg float4 column groups x (256/cg) row lanes of one row chunk
@@ -155,7 +203,6 @@ struct FBnBwd {
     }
 };
 
-__device__ __forceinline__ int perm16(int c, int perm_c0) { return perm_c0 > 0 ? (c % perm_c0) * 16 + c / perm_c0 : c; }
 
 __global__ __launch_bounds__(1024) void k_colsum_fin(const float* __restrict__ p0, int nch, int C, float* __restrict__ out) {
     __shared__ float sh[2][16][64];

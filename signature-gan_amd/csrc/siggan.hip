@@ -56,7 +56,7 @@ struct siggan_ctx {
     bool g_dirty, d_dirty;
     // workspace
     char* ws; size_t ws_bytes;
-    float *z, *fc_y, *g_y[MAXL + 1], *g_a[MAXL + 1], *g_da[MAXL + 1], *g_bn[MAXL + 1];
+    float *z, *fc_y, *g_y[MAXL + 1], *g_a[MAXL + 1], *g_da[MAXL + 1], *g_bn[MAXL + 1], *g_bne[MAXL + 1];
     float *img, *dpre;
     float *d_a[MAXL + 1], *d_dv[MAXL + 1], *d_noise[MAXL + 1];
     float *logits, *probs, *dlogit;
@@ -158,6 +158,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
             carve(&c->g_a[l], n);
             carve(&c->g_da[l], n);
             carve(&c->g_bn[l], 6 * (int64_t)(l == 0 ? c->F : c->gC[l]));
+            carve(&c->g_bne[l], 4 * (int64_t)(l == 0 ? c->F : c->gC[l]));   // eval-mode [scale|shift|mean|rstd]
         }
         if (pass == 1) c->g_y[0] = c->fc_y;
         carve(&c->img, Bm * c->S * c->S);
@@ -264,23 +265,51 @@ static int check_call(siggan_ctx* c, int batch, bool need_bound = true) {
     return SIGGAN_OK;
 }
 
-static void repack(siggan_ctx* c, hipStream_t s) {
-    if (c->g_dirty) {
-        launch_fc_pack(GP(c, gi_fc_w()), c->wfc_t, c->latent, c->gC[0], s);
+// One launch per network rebuilds everything derived from its arena: GEMM-friendly weight copies and
+// (for G) the BatchNorm eval-mode scale/shift tables.
+static void repack(siggan_ctx* c, hipStream_t s, bool force = false) {
+    if (c->g_dirty || force) {
+        PrepTable t; t.njobs = 0;
+        PrepJob j; memset(&j, 0, sizeof j);
+        j.type = PREP_FC_T; j.O = c->latent; j.I = c->gC[0]; j.src = GP(c, gi_fc_w()); j.dst = c->wfc_t;
+        prep_add(t, j, (long long)c->latent * c->F);
         for (int l = 1; l <= c->Lg; ++l) {
-            const float* w = GP(c, gi_up_w(l));                       // (Cin, Cout, 4, 4)
-            launch_pack_up(w, c->g_up[l], c->gC[l - 1], c->gC[l], s);   // forward: contract Cin
-            launch_pack_down(w, c->g_dn[l], c->gC[l - 1], c->gC[l], s); // input-gradient: out = Cin, contract Cout
+            const long long n = (long long)c->gC[l - 1] * c->gC[l] * 16;
+            memset(&j, 0, sizeof j);
+            j.src = GP(c, gi_up_w(l));                                 // (Cin, Cout, 4, 4)
+            j.type = PREP_PACK_UP; j.I = c->gC[l - 1]; j.O = c->gC[l]; j.dst = c->g_up[l];   // forward: contract Cin
+            prep_add(t, j, n);
+            j.type = PREP_PACK_DOWN; j.O = c->gC[l - 1]; j.I = c->gC[l]; j.dst = c->g_dn[l]; // input-gradient: out = Cin
+            prep_add(t, j, n);
         }
+        for (int l = 0; l <= c->Lg; ++l) {
+            const int C = l == 0 ? c->F : c->gC[l];
+            memset(&j, 0, sizeof j);
+            j.type = PREP_BN_EVAL; j.O = C; j.perm = l == 0 ? c->gC[0] : 0;
+            j.src = GP(c, gi_bn_w(l)); j.src2 = GP(c, gi_bn_b(l));
+            j.src3 = c->st.g_bn_running_mean + c->g_bn_off[l]; j.src4 = c->st.g_bn_running_var + c->g_bn_off[l];
+            j.dst = c->g_bne[l];
+            prep_add(t, j, C);
+        }
+        launch_prepare(t, BN_EPS, s);
         c->g_dirty = false;
     }
-    if (c->d_dirty) {
+    if (c->d_dirty || force) {
+        PrepTable t; t.njobs = 0;
+        PrepJob j;
         for (int l = 2; l <= c->Ld; ++l) {
-            const float* w = DP(c, di_w(l));                          // (Cout, Cin, 4, 4)
-            launch_pack_down(w, c->d_dn[l], c->dC[l], c->dC[l - 1], s); // forward
-            launch_pack_up(w, c->d_up[l], c->dC[l], c->dC[l - 1], s);   // input-gradient: contract Cout, produce Cin
+            const long long n = (long long)c->dC[l - 1] * c->dC[l] * 16;
+            memset(&j, 0, sizeof j);
+            j.src = DP(c, di_w(l));                                    // (Cout, Cin, 4, 4)
+            j.type = PREP_PACK_DOWN; j.O = c->dC[l]; j.I = c->dC[l - 1]; j.dst = c->d_dn[l];  // forward
+            prep_add(t, j, n);
+            j.type = PREP_PACK_UP; j.I = c->dC[l]; j.O = c->dC[l - 1]; j.dst = c->d_up[l];    // input-gradient: contract Cout
+            prep_add(t, j, n);
         }
-        launch_cls_pack(DP(c, di_cls_w(c)), c->wcp, c->dC[c->Ld], s);
+        memset(&j, 0, sizeof j);
+        j.type = PREP_CLS; j.O = c->dC[c->Ld]; j.src = DP(c, di_cls_w(c)); j.dst = c->wcp;
+        prep_add(t, j, (long long)c->dC[c->Ld] * 16);
+        launch_prepare(t, BN_EPS, s);
         c->d_dirty = false;
     }
 }
@@ -288,15 +317,12 @@ static void repack(siggan_ctx* c, hipStream_t s) {
 // Generator.forward (generator_vanilla_gan.py:189-209).  training: BN batch stats (+ running
 // update) and raw pre-BN outputs kept for the backward pass; eval: BN folded into the epilogue.
 static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s) {
-    const float* rm = c->st.g_bn_running_mean; const float* rv = c->st.g_bn_running_var;
     launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s);
     if (training)
         launch_bn_train_stats(c->fc_y, B, c->F, GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), c->st.g_bn_running_mean,
                               c->st.g_bn_running_var, c->st.g_bn_batches, c->g_bn[0], c->partial, c->gC[0], BN_MOMENTUM,
                               BN_EPS, s);
-    else
-        launch_bn_eval_affine(GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), rm, rv, c->g_bn[0], c->F, c->gC[0], BN_EPS, s);
-    launch_bn_relu(c->fc_y, c->g_a[0], B, c->F, c->g_bn[0], s);
+    launch_bn_relu(c->fc_y, c->g_a[0], B, c->F, training ? c->g_bn[0] : c->g_bne[0], s);
     for (int l = 1; l <= c->Lg; ++l) {
         const int Hi = 4 << (l - 1), Ci = c->gC[l - 1], Co = c->gC[l];
         GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
@@ -313,12 +339,12 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
                                   BN_MOMENTUM, BN_EPS, s);
             launch_bn_relu(c->g_y[l], c->g_a[l], R, C, c->g_bn[l], s);
         } else {
-            launch_bn_eval_affine(GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), rm + off, rv + off, c->g_bn[l], C, 0, BN_EPS, s);
-            a.out = c->g_a[l]; a.epi = EPI_AFFINE_RELU; a.scale = c->g_bn[l]; a.shift = c->g_bn[l] + C;
+            a.out = c->g_a[l]; a.epi = EPI_AFFINE_RELU; a.scale = c->g_bne[l]; a.shift = c->g_bne[l] + C;
             launch_gconv(a, s);
         }
     }
     launch_final_fwd(c->g_a[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
+    if (training) c->g_dirty = true;   // running statistics moved: the eval-mode tables are stale
 }
 
 // Discriminator conv blocks + classifier logits over Bd images given as two segments.
