@@ -120,6 +120,12 @@ int siggan_bind(siggan_ctx *ctx, const siggan_storage *st);
  * (load_state_dict, manual edits): packed weight copies are rebuilt on next use */
 int siggan_params_changed(siggan_ctx *ctx);
 int siggan_seed(siggan_ctx *ctx, uint64_t seed, uint64_t offset);
+/* execution mode of the step phases (default: SIGGAN_MODE_OVERLAP): SIGGAN_MODE_GRAPH replays each phase as a
+ * hipGraph captured once per distinct (batch, flags, hyper-parameters); SIGGAN_MODE_OVERLAP runs
+ * the weight-gradient / reduction kernels on side streams beside the input-gradient chain. */
+#define SIGGAN_MODE_GRAPH 1
+#define SIGGAN_MODE_OVERLAP 2
+int siggan_set_mode(siggan_ctx *ctx, int32_t mode);
 
 /* ---- forward passes ---------------------------------------------------------------------- */
 /* z_dev (B,latent) -> images_dev (B,1,S,S) in [-1,1].  training!=0: BatchNorm batch statistics,

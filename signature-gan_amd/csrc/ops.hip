@@ -70,35 +70,63 @@ __device__ __forceinline__ int perm16(int c, int perm_c0) { return perm_c0 > 0 ?
 // =========================================================================================
 // fused prepare pass (weight packs, fc / classifier permutes, BatchNorm eval folding)
 // =========================================================================================
-void prep_add(PrepTable& t, const PrepJob& j, long long count) {
+// One workgroup = one unit of a job; every unit is a small transpose staged through LDS so that both
+// the global reads and the global writes are contiguous runs:
+//   PACK_DOWN  unit = output channel o : w[o][i][tap]     -> dst[o][tap*I + i]          (I*16 floats)
+//   PACK_UP    unit = output channel o : w[i][o][kh][kw]  -> dst[cls][o][t*I + i]       (I*16 floats)
+//   FC_T       unit = 64 features x <=128 latent dims    : W[f][k] -> Wt[k][f']
+//   BN_EVAL    unit = 256 channels
+static long long prep_units(const PrepJob& j) {
+    switch (j.type) {
+        case PREP_PACK_DOWN: case PREP_CLS: return j.type == PREP_CLS ? 1 : j.O;
+        case PREP_PACK_UP: return j.O;
+        case PREP_FC_T: return (long long)(j.I * 16 / 64) * ((j.O + 127) / 128);
+        default: return (j.O + 255) / 256;
+    }
+}
+void prep_add(PrepTable& t, const PrepJob& j, long long /*count*/) {
     if (t.njobs >= PrepTable::MAXJ) return;
     if (t.njobs == 0) t.prefix[0] = 0;
     t.job[t.njobs] = j;
-    t.prefix[t.njobs + 1] = t.prefix[t.njobs] + count;
+    t.prefix[t.njobs + 1] = t.prefix[t.njobs] + prep_units(j);
     ++t.njobs;
 }
 __global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
-    const long long total = t.prefix[t.njobs];
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        int j = 0;
-        while (idx >= t.prefix[j + 1]) ++j;
-        const PrepJob& q = t.job[j];
-        const long long i = idx - t.prefix[j];
-        if (q.type == PREP_PACK_DOWN) {            // w[o][i][tap] -> dst[o][tap*I + i]
-            const int ci = (int)(i % q.I), tap = (int)((i / q.I) % 16), o = (int)(i / ((long long)q.I * 16));
-            q.dst[i] = q.src[((size_t)o * q.I + ci) * 16 + tap];
-        } else if (q.type == PREP_PACK_UP) {       // w[i][o][kh][kw] -> dst[cls][o][(th*2+tw)*I + i]
-            const int ci = (int)(i % q.I), tt = (int)((i / q.I) % 4), o = (int)((i / ((long long)q.I * 4)) % q.O);
-            const int cls = (int)(i / ((long long)q.I * 4 * q.O));
+    extern __shared__ float tile[];
+    int j = 0;
+    while ((long long)blockIdx.x >= t.prefix[j + 1]) ++j;
+    const PrepJob& q = t.job[j];
+    const int u = (int)(blockIdx.x - t.prefix[j]);
+    const int tid = threadIdx.x;
+    if (q.type == PREP_PACK_DOWN || q.type == PREP_CLS) {
+        const int I = q.type == PREP_CLS ? q.O : q.I;
+        const float* src = q.src + (size_t)u * I * 16;
+        for (int e = tid; e < I * 16; e += 256) tile[(e >> 4) * 17 + (e & 15)] = src[e];
+        __syncthreads();
+        float* dst = q.dst + (size_t)u * I * 16;
+        for (int e = tid; e < I * 16; e += 256) { const int tap = e / I, i = e - tap * I; dst[e] = tile[i * 17 + tap]; }
+    } else if (q.type == PREP_PACK_UP) {
+        const int I = q.I, O = q.O;
+        for (int e = tid; e < I * 16; e += 256) tile[(e >> 4) * 17 + (e & 15)] = q.src[((size_t)(e >> 4) * O + u) * 16 + (e & 15)];
+        __syncthreads();
+        for (int e = tid; e < I * 16; e += 256) {
+            const int i = e % I, tt = (e / I) & 3, cls = e / (4 * I);
             const int kh = 1 - (cls >> 1) + 2 * (tt >> 1), kw = 1 - (cls & 1) + 2 * (tt & 1);
-            q.dst[i] = q.src[((size_t)ci * q.O + o) * 16 + kh * 4 + kw];
-        } else if (q.type == PREP_FC_T) {          // Wt[k][f'] = W[f][k], K = q.O, C0 = q.I
-            const int F = q.I * 16, fp = (int)(i % F), k = (int)(i / F);
-            q.dst[i] = q.src[(size_t)((fp % q.I) * 16 + fp / q.I) * q.O + k];
-        } else if (q.type == PREP_CLS) {           // wcp[hw*C + c] = Wc[c*16 + hw]
-            q.dst[i] = q.src[(i % q.O) * 16 + i / q.O];
-        } else {                                   // BN eval: [scale | shift | mean | rstd]
-            const int C = q.O, c = (int)i, tix = perm16(c, q.perm);
+            q.dst[((size_t)cls * O + u) * 4 * I + tt * I + i] = tile[i * 17 + kh * 4 + kw];
+        }
+    } else if (q.type == PREP_FC_T) {            // K = q.O, C0 = q.I
+        const int K = q.O, C0 = q.I, F = C0 * 16, kchunks = (K + 127) / 128;
+        const int f0 = (u / kchunks) * 64, k0 = (u % kchunks) * 128, kn = min(128, K - k0);
+        for (int e = tid; e < 64 * kn; e += 256) {
+            const int r = e / kn, k = e - r * kn, fp = f0 + r;
+            tile[r * 129 + k] = q.src[(size_t)((fp % C0) * 16 + fp / C0) * K + k0 + k];
+        }
+        __syncthreads();
+        for (int e = tid; e < 64 * kn; e += 256) { const int k = e >> 6, r = e & 63; q.dst[(size_t)(k0 + k) * F + f0 + r] = tile[r * 129 + k]; }
+    } else {                                     // BN eval: [scale | shift | mean | rstd]
+        const int C = q.O, c = u * 256 + tid;
+        if (c < C) {
+            const int tix = perm16(c, q.perm);
             const float rstd = 1.0f / sqrtf(q.src4[tix] + eps);
             const float sc = q.src[tix] * rstd;
             q.dst[c] = sc; q.dst[C + c] = q.src2[tix] - q.src3[tix] * sc; q.dst[2 * C + c] = q.src3[tix]; q.dst[3 * C + c] = rstd;
@@ -107,10 +135,8 @@ __global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
 }
 void launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s) {
     if (t.njobs == 0) return;
-    long long total = t.prefix[t.njobs];
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_prepare, dim3(blocks), dim3(256), 0, s, t, bn_eps);
+    // LDS: 512 input channels x 17 floats (conv packs) or 64 x 129 (fc) -- 34.8 KB
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)t.prefix[t.njobs]), dim3(256), 512 * 17 * sizeof(float), s, t, bn_eps);
 }
 
 // =========================================================================================
@@ -388,67 +414,84 @@ void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int 
 // =========================================================================================
 // Generator final 3x3 conv (C -> 1) + tanh
 // =========================================================================================
+// 8 lanes per pixel (4 channels each, weights in registers), 8 pixels per lane group: every tap is
+// one coalesced 128-byte read per pixel; the 8 partial dot products are combined with shuffles.
 __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ act, const float* __restrict__ W,
                                                    const float* __restrict__ b, float* __restrict__ img, int B, int S,
                                                    int C) {
-    extern __shared__ __attribute__((aligned(16))) float sW[];   // [9][C]
-    for (int i = threadIdx.x; i < 9 * C; i += 256) sW[i] = W[(i % C) * 9 + i / C];
-    __syncthreads();
-    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (pix >= (int64_t)B * S * S) return;
-    const int w = (int)(pix % S), h = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
-    float acc = 0.f;
-    for (int kh = 0; kh < 3; ++kh) {
-        const int hh = h + kh - 1;
-        if ((unsigned)hh >= (unsigned)S) continue;
-        for (int kw = 0; kw < 3; ++kw) {
-            const int ww = w + kw - 1;
-            if ((unsigned)ww >= (unsigned)S) continue;
-            const float4* ap = (const float4*)(act + (((size_t)n * S + hh) * S + ww) * C);
-            const float4* wp = (const float4*)(sW + (kh * 3 + kw) * C);
-            for (int c = 0; c < C / 4; ++c) {
-                const float4 x = ap[c], ww4 = wp[c];
-                acc = fmaf(x.x, ww4.x, acc); acc = fmaf(x.y, ww4.y, acc);
-                acc = fmaf(x.z, ww4.z, acc); acc = fmaf(x.w, ww4.w, acc);
+    const int G = C / 4;                               // lanes per pixel (8 for C = 32)
+    const int c4 = threadIdx.x % G, grp = threadIdx.x / G, ngrp = 256 / G;
+    float4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        w[t] = make_float4(W[(c4 * 4 + 0) * 9 + t], W[(c4 * 4 + 1) * 9 + t], W[(c4 * 4 + 2) * 9 + t], W[(c4 * 4 + 3) * 9 + t]);
+    const float bias = b[0];
+    const int64_t total = (int64_t)B * S * S;
+    const int64_t base = (int64_t)blockIdx.x * ngrp * 8;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int64_t pix = base + it * ngrp + grp;
+        float acc = 0.f;
+        if (pix < total) {
+            const int x = (int)(pix % S), y = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int yy = y + kh - 1;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int xx = x + kw - 1;
+                    if ((unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S) {
+                        const float4 v = *(const float4*)(act + (((size_t)n * S + yy) * S + xx) * C + c4 * 4);
+                        const float4 ww = w[kh * 3 + kw];
+                        acc = fmaf(v.x, ww.x, acc); acc = fmaf(v.y, ww.y, acc); acc = fmaf(v.z, ww.z, acc); acc = fmaf(v.w, ww.w, acc);
+                    }
+                }
             }
         }
+        for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+        if (pix < total && c4 == 0) img[pix] = tanhf(acc + bias);
     }
-    img[pix] = tanhf(acc + b[0]);
 }
 void launch_final_fwd(const float* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s) {
-    hipLaunchKernelGGL(k_final_fwd, dim3(cdiv((int64_t)B * S * S, 256)), dim3(256), 9 * C * sizeof(float), s, act, W, b,
-                       img, B, S, C);
+    const int ppb = (256 / (C / 4)) * 8;
+    hipLaunchKernelGGL(k_final_fwd, dim3(cdiv((int64_t)B * S * S, ppb)), dim3(256), 0, s, act, W, b, img, B, S, C);
 }
 
 __global__ __launch_bounds__(256) void k_final_dgrad(const float* __restrict__ dpre, const float* __restrict__ W,
                                                      float* __restrict__ dact, int B, int S, int C) {
-    extern __shared__ __attribute__((aligned(16))) float sW[];   // [9][C]
-    for (int i = threadIdx.x; i < 9 * C; i += 256) sW[i] = W[(i % C) * 9 + i / C];
-    __syncthreads();
-    const int C4 = C / 4;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)B * S * S * C4) return;
-    const int c4 = (int)(idx % C4);
-    const int64_t pix = idx / C4;
-    const int w = (int)(pix % S), h = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int kh = 0; kh < 3; ++kh) {
-        const int hh = h + 1 - kh;
-        if ((unsigned)hh >= (unsigned)S) continue;
-        for (int kw = 0; kw < 3; ++kw) {
-            const int ww = w + 1 - kw;
-            if ((unsigned)ww >= (unsigned)S) continue;
-            const float d = dpre[((size_t)n * S + hh) * S + ww];
-            const float4 wv = *(const float4*)(sW + (kh * 3 + kw) * C + c4 * 4);
-            acc.x = fmaf(d, wv.x, acc.x); acc.y = fmaf(d, wv.y, acc.y);
-            acc.z = fmaf(d, wv.z, acc.z); acc.w = fmaf(d, wv.w, acc.w);
+    const int G = C / 4;
+    const int c4 = threadIdx.x % G, grp = threadIdx.x / G, ngrp = 256 / G;
+    float4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        w[t] = make_float4(W[(c4 * 4 + 0) * 9 + t], W[(c4 * 4 + 1) * 9 + t], W[(c4 * 4 + 2) * 9 + t], W[(c4 * 4 + 3) * 9 + t]);
+    const int64_t total = (int64_t)B * S * S;
+    const int64_t base = (int64_t)blockIdx.x * ngrp * 8;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int64_t pix = base + it * ngrp + grp;
+        if (pix >= total) break;
+        const int x = (int)(pix % S), y = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = y + 1 - kh;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xx = x + 1 - kw;
+                if ((unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S) {
+                    const float d = dpre[((size_t)n * S + yy) * S + xx];
+                    const float4 ww = w[kh * 3 + kw];
+                    acc.x = fmaf(d, ww.x, acc.x); acc.y = fmaf(d, ww.y, acc.y); acc.z = fmaf(d, ww.z, acc.z); acc.w = fmaf(d, ww.w, acc.w);
+                }
+            }
         }
+        *(float4*)(dact + (size_t)pix * C + c4 * 4) = acc;
     }
-    ((float4*)dact)[idx] = acc;
 }
 void launch_final_dgrad(const float* dpre, const float* W, float* dact, int B, int S, int C, hipStream_t s) {
-    hipLaunchKernelGGL(k_final_dgrad, dim3(cdiv((int64_t)B * S * S * (C / 4), 256)), dim3(256), 9 * C * sizeof(float), s,
-                       dpre, W, dact, B, S, C);
+    const int ppb = (256 / (C / 4)) * 8;
+    hipLaunchKernelGGL(k_final_dgrad, dim3(cdiv((int64_t)B * S * S, ppb)), dim3(256), 0, s, dpre, W, dact, B, S, C);
 }
 
 // block = C channel lanes x (256/C) pixel lanes; partial[chunk][C*9 + 1]
@@ -521,46 +564,53 @@ __device__ __forceinline__ const float* seg_ptr(const float* x0, int n0, const f
     return n < n0 ? x0 + (size_t)n * S * S : x1 + (size_t)(n - n0) * S * S;
 }
 
+// thread = 4 output channels (16 taps x 4 weights in registers) x 8 output pixels; the 16 lanes
+// of a pixel read the same 16 input values (broadcast) and write 256 contiguous bytes.
 __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x0, int n0, const float* __restrict__ x1,
                                                    const float* __restrict__ W, const float* __restrict__ b,
                                                    const float* __restrict__ noise, float slope,
                                                    float* __restrict__ out, int B, int S, int C) {
-    extern __shared__ __attribute__((aligned(16))) float sW[];   // [16][C] then bias [C]
-    for (int i = threadIdx.x; i < 16 * C; i += 256) sW[i] = W[(i % C) * 16 + i / C];
-    for (int i = threadIdx.x; i < C; i += 256) sW[16 * C + i] = b[i];
-    __syncthreads();
-    const int Q = C / 4, ppb = 256 / Q, Ho = S / 2;
-    const int q = threadIdx.x % Q, pl = threadIdx.x / Q;
-    const int64_t pix = (int64_t)blockIdx.x * ppb + pl;
-    if (pix >= (int64_t)B * Ho * Ho) return;
-    const int ow = (int)(pix % Ho), oh = (int)((pix / Ho) % Ho), n = (int)(pix / ((int64_t)Ho * Ho));
-    const float* xp = seg_ptr(x0, n0, x1, n, S);
-    float4 acc = *(const float4*)(sW + 16 * C + q * 4);
+    const int Q = C / 4, ngrp = 256 / Q, Ho = S / 2;
+    const int q = threadIdx.x % Q, grp = threadIdx.x / Q;
+    float4 w[16];
 #pragma unroll
-    for (int kh = 0; kh < 4; ++kh) {
-        const int ih = 2 * oh - 1 + kh;
+    for (int t = 0; t < 16; ++t)
+        w[t] = make_float4(W[(q * 4 + 0) * 16 + t], W[(q * 4 + 1) * 16 + t], W[(q * 4 + 2) * 16 + t], W[(q * 4 + 3) * 16 + t]);
+    const float4 bias = *(const float4*)(b + q * 4);
+    const int64_t total = (int64_t)B * Ho * Ho;
+    const int64_t base = (int64_t)blockIdx.x * ngrp * 8;
+    for (int it = 0; it < 8; ++it) {
+        const int64_t pix = base + it * ngrp + grp;
+        if (pix >= total) break;
+        const int ow = (int)(pix % Ho), oh = (int)((pix / Ho) % Ho), n = (int)(pix / ((int64_t)Ho * Ho));
+        const float* xp = seg_ptr(x0, n0, x1, n, S);
+        float4 acc = bias;
 #pragma unroll
-        for (int kw = 0; kw < 4; ++kw) {
-            const int iw = 2 * ow - 1 + kw;
-            const float xv = ((unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) ? xp[ih * S + iw] : 0.f;
-            const float4 wv = *(const float4*)(sW + (kh * 4 + kw) * C + q * 4);
-            acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
-            acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+        for (int kh = 0; kh < 4; ++kh) {
+            const int ih = 2 * oh - 1 + kh;
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int iw = 2 * ow - 1 + kw;
+                const float xv = ((unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) ? xp[ih * S + iw] : 0.f;
+                const float4 wv = w[kh * 4 + kw];
+                acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
+                acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+            }
         }
+        acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
+        acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
+        if (noise) {
+            const float4 nz = *(const float4*)(noise + (size_t)n * C + q * 4);
+            acc.x *= nz.x; acc.y *= nz.y; acc.z *= nz.z; acc.w *= nz.w;
+        }
+        *(float4*)(out + (size_t)pix * C + q * 4) = acc;
     }
-    acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
-    acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
-    if (noise) {
-        const float4 nz = *(const float4*)(noise + (size_t)n * C + q * 4);
-        acc.x *= nz.x; acc.y *= nz.y; acc.z *= nz.z; acc.w *= nz.w;
-    }
-    *(float4*)(out + (size_t)pix * C + q * 4) = acc;
 }
 void launch_conv1_fwd(const float* x0, int n0, const float* x1, const float* W, const float* b, const float* noise,
                       float slope, float* out, int B, int S, int C, hipStream_t s) {
-    const int ppb = 256 / (C / 4);
-    hipLaunchKernelGGL(k_conv1_fwd, dim3(cdiv((int64_t)B * (S / 2) * (S / 2), ppb)), dim3(256), 17 * C * sizeof(float), s,
-                       x0, n0, x1, W, b, noise, slope, out, B, S, C);
+    const int ppb = (256 / (C / 4)) * 8;
+    hipLaunchKernelGGL(k_conv1_fwd, dim3(cdiv((int64_t)B * (S / 2) * (S / 2), ppb)), dim3(256), 0, s, x0, n0, x1, W, b, noise,
+                       slope, out, B, S, C);
 }
 
 // block = C channel lanes x (256/C) pixel lanes; partial[chunk][C*17]  (16 taps + bias)

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -41,6 +42,17 @@ static const int MAXL = 6;
 
 static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+struct PhaseKey {
+    int phase, B, has_z, has_masks, g_dirty, d_dirty;
+    double lr, beta1, beta2, eps;
+    float ls, clip, gs;
+    bool operator==(const PhaseKey& o) const {
+        return phase == o.phase && B == o.B && has_z == o.has_z && has_masks == o.has_masks && g_dirty == o.g_dirty &&
+               d_dirty == o.d_dirty && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
+               clip == o.clip && gs == o.gs;
+    }
+};
+
 struct siggan_ctx {
     siggan_config cfg;
     int S, latent, Lg, Ld, Bm;
@@ -61,11 +73,18 @@ struct siggan_ctx {
     float *d_a[MAXL + 1], *d_dv[MAXL + 1], *d_noise[MAXL + 1];
     float *logits, *probs, *dlogit;
     float *g_up[MAXL + 1], *g_dn[MAXL + 1], *d_dn[MAXL + 1], *d_up[MAXL + 1], *wcp;
-    float *slab, *partial, *metrics, *op_pack, *zeros, *wfc_t;
-    int64_t slab_floats;
+    float *slab, *slab_k, *slab_k2, *partial, *partial_b, *metrics, *op_pack, *zeros, *wfc_t, *real_stage, *mask_stage;
+    int64_t slab_floats, slab_k_floats;
     DevState* dev;
     // last *_grads call (for *_apply)
     int pending;   // 0 none, 1 D, 2 G
+    // lanes / graphs
+    static constexpr int NEV = 96;
+    int mode;
+    hipStream_t s_m, s_a, s_b;
+    hipEvent_t ev[NEV], ev_bridge[2];
+    int evi;
+    std::vector<std::pair<PhaseKey, hipGraphExec_t>> graphs;
 };
 
 // parameter tensor indices
@@ -148,6 +167,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         off += ((size_t)nfloats * sizeof(float) + 255) & ~(size_t)255;
     };
     c->slab_floats = (int64_t)16 << 20;
+    c->slab_k_floats = (int64_t)16 << 20;
     for (int pass = 0; pass < 2; ++pass) {
         off = 0;
         carve(&c->z, Bm * c->latent);
@@ -180,7 +200,12 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         }
         carve(&c->wcp, (int64_t)c->dC[c->Ld] * 16);
         carve(&c->slab, c->slab_floats);
+        carve(&c->slab_k, c->slab_k_floats);
+        carve(&c->slab_k2, c->slab_k_floats);
         carve(&c->partial, (int64_t)2 << 20);
+        carve(&c->partial_b, (int64_t)2 << 20);
+        carve(&c->real_stage, Bm * c->S * c->S);
+        { int64_t sumC = 0; for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l]; carve(&c->mask_stage, 2 * Bm * sumC); }
         carve(&c->metrics, SIGGAN_M_COUNT);
         carve(&c->op_pack, (int64_t)512 * 512 * 16);
         carve(&c->zeros, 64);
@@ -199,14 +224,29 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     DevState h; memset(&h, 0, sizeof h);
     h.seed = cfg->seed; h.rng_ctr = 0; h.grad_mul = 1.f;
     HIPCHK(hipMemcpy(c->dev, &h, sizeof h, hipMemcpyHostToDevice));
+    if (const char* e = getenv("SIGGAN_GCONV_DMA")) g_gconv_dma = atoi(e);   // A/B switch of the conv staging path
+    c->mode = SIGGAN_MODE_OVERLAP;   // hipGraph replay measured slower than eager launches on ROCm 7
+    c->evi = 0;
+    HIPCHK(hipStreamCreateWithFlags(&c->s_m, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->s_a, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->s_b, hipStreamNonBlocking));
+    for (int i = 0; i < siggan_ctx::NEV; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_bridge[i], hipEventDisableTiming));
     *out = c;
     return SIGGAN_OK;
 }
 
 extern "C" int siggan_destroy(siggan_ctx* c) {
     if (!c) return SIGGAN_OK;
-    hipSetDevice(c->cfg.device);
-    if (c->ws) hipFree(c->ws);
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto& e : c->graphs) (void)hipGraphExecDestroy(e.second);
+    for (int i = 0; i < siggan_ctx::NEV; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2; ++i) if (c->ev_bridge[i]) (void)hipEventDestroy(c->ev_bridge[i]);
+    if (c->s_m) (void)hipStreamDestroy(c->s_m);
+    if (c->s_a) (void)hipStreamDestroy(c->s_a);
+    if (c->s_b) (void)hipStreamDestroy(c->s_b);
+    if (c->ws) (void)hipFree(c->ws);
     delete c;
     return SIGGAN_OK;
 }
@@ -266,9 +306,9 @@ static int check_call(siggan_ctx* c, int batch, bool need_bound = true) {
 }
 
 // One launch per network rebuilds everything derived from its arena: GEMM-friendly weight copies and
-// (for G) the BatchNorm eval-mode scale/shift tables.
-static void repack(siggan_ctx* c, hipStream_t s, bool force = false) {
-    if (c->g_dirty || force) {
+// (for G) the BatchNorm eval-mode scale/shift tables.  sg / sd: the lanes the two launches go to.
+static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, bool do_d) {
+    if (do_g) {
         PrepTable t; t.njobs = 0;
         PrepJob j; memset(&j, 0, sizeof j);
         j.type = PREP_FC_T; j.O = c->latent; j.I = c->gC[0]; j.src = GP(c, gi_fc_w()); j.dst = c->wfc_t;
@@ -291,10 +331,9 @@ static void repack(siggan_ctx* c, hipStream_t s, bool force = false) {
             j.dst = c->g_bne[l];
             prep_add(t, j, C);
         }
-        launch_prepare(t, BN_EPS, s);
-        c->g_dirty = false;
+        launch_prepare(t, BN_EPS, sg);
     }
-    if (c->d_dirty || force) {
+    if (do_d) {
         PrepTable t; t.njobs = 0;
         PrepJob j;
         for (int l = 2; l <= c->Ld; ++l) {
@@ -309,9 +348,36 @@ static void repack(siggan_ctx* c, hipStream_t s, bool force = false) {
         memset(&j, 0, sizeof j);
         j.type = PREP_CLS; j.O = c->dC[c->Ld]; j.src = DP(c, di_cls_w(c)); j.dst = c->wcp;
         prep_add(t, j, (long long)c->dC[c->Ld] * 16);
-        launch_prepare(t, BN_EPS, s);
-        c->d_dirty = false;
+        launch_prepare(t, BN_EPS, sd);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// lanes: where a phase enqueues its kernels.  m is the main lane; a and b are side lanes that run
+// independent work (weight gradients, bias / BatchNorm reductions) beside the main chain.  With
+// overlap off all three are the same stream and fork/join are no-ops.  Forks and joins are plain
+// event record / wait pairs, so the same code runs eagerly and under stream capture (hipGraph).
+// ------------------------------------------------------------------------------------------
+struct Lanes {
+    siggan_ctx* c;
+    hipStream_t m, a, b;
+    hipEvent_t next() { hipEvent_t e = c->ev[c->evi]; c->evi = (c->evi + 1) % siggan_ctx::NEV; return e; }
+    void fork(hipStream_t to) {          // `to` waits for everything enqueued on m so far
+        if (to == m) return;
+        hipEvent_t e = next();
+        (void)hipEventRecord(e, m); (void)hipStreamWaitEvent(to, e, 0);
+    }
+    void join(hipStream_t from) {        // m waits for everything enqueued on `from`
+        if (from == m) return;
+        hipEvent_t e = next();
+        (void)hipEventRecord(e, from); (void)hipStreamWaitEvent(m, e, 0);
+    }
+};
+
+static GConvArgs gconv_args(siggan_ctx* c) {
+    GConvArgs a; memset(&a, 0, sizeof a);
+    a.slab = c->slab_k; a.slab_floats = c->slab_k_floats; a.zeros = c->zeros;
+    return a;
 }
 
 // Generator.forward (generator_vanilla_gan.py:189-209).  training: BN batch stats (+ running
@@ -325,7 +391,7 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
     launch_bn_relu(c->fc_y, c->g_a[0], B, c->F, training ? c->g_bn[0] : c->g_bne[0], s);
     for (int l = 1; l <= c->Lg; ++l) {
         const int Hi = 4 << (l - 1), Ci = c->gC[l - 1], Co = c->gC[l];
-        GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
+        GConvArgs a = gconv_args(c);
         a.in = c->g_a[l - 1]; a.wp = c->g_up[l]; a.B = B; a.Hi = Hi; a.Wi = Hi; a.Ci = Ci; a.Co = Co;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = 2 * Hi; a.Wo = 2 * Hi; a.form = 1; a.M = B * Hi * Hi;
         const int C = Co;
@@ -344,85 +410,101 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
         }
     }
     launch_final_fwd(c->g_a[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
-    if (training) c->g_dirty = true;   // running statistics moved: the eval-mode tables are stale
 }
 
-// Discriminator conv blocks + classifier logits over Bd images given as two segments.
-static void d_forward_pass(siggan_ctx* c, const float* x0, int n0, const float* x1, int Bd, bool dropout, hipStream_t s) {
+// Discriminator conv blocks + classifier logits for nB images written to workspace rows
+// [r0, r0 + nB) (the D step runs D(real) into rows [0,B) on a side lane while the Generator
+// produces the fakes, then D(fake) into rows [B,2B); backward treats the 2B rows as one batch).
+static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool dropout, hipStream_t s, float* slab_k) {
     const float slope = c->cfg.leaky_slope;
-    launch_conv1_fwd(x0, n0, x1, DP(c, di_w(1)), DP(c, di_b(1)), dropout ? c->d_noise[1] : nullptr, slope, c->d_a[1], Bd,
-                     c->S, c->dC[1], s);
+    auto act = [&](int l) { const int64_t H = c->S >> l; return c->d_a[l] + (int64_t)r0 * H * H * c->dC[l]; };
+    auto nz = [&](int l) { return dropout ? c->d_noise[l] + (int64_t)r0 * c->dC[l] : nullptr; };
+    launch_conv1_fwd(x, nB, x, DP(c, di_w(1)), DP(c, di_b(1)), nz(1), slope, act(1), nB, c->S, c->dC[1], s);
     for (int l = 2; l <= c->Ld; ++l) {
         const int Hi = c->S >> (l - 1), Ho = Hi / 2;
-        GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
-        a.in = c->d_a[l - 1]; a.wp = c->d_dn[l]; a.out = c->d_a[l];
-        a.B = Bd; a.Hi = Hi; a.Wi = Hi; a.Ci = c->dC[l - 1]; a.Co = c->dC[l];
-        a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Ho; a.Wo = Ho; a.form = 0; a.M = Bd * Ho * Ho;
-        a.epi = EPI_BIAS_LRELU_DROP; a.bias = DP(c, di_b(l)); a.noise = dropout ? c->d_noise[l] : nullptr; a.slope = slope;
+        GConvArgs a = gconv_args(c);
+        a.slab = slab_k;
+        a.in = act(l - 1); a.wp = c->d_dn[l]; a.out = act(l);
+        a.B = nB; a.Hi = Hi; a.Wi = Hi; a.Ci = c->dC[l - 1]; a.Co = c->dC[l];
+        a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Ho; a.Wo = Ho; a.form = 0; a.M = nB * Ho * Ho;
+        a.epi = EPI_BIAS_LRELU_DROP; a.bias = DP(c, di_b(l)); a.noise = nz(l); a.slope = slope;
         launch_gconv(a, s);
     }
-    launch_cls_fwd(c->d_a[c->Ld], c->wcp, DP(c, di_cls_b(c)), c->logits, Bd, c->dC[c->Ld] * 16, s);
+    launch_cls_fwd(act(c->Ld), c->wcp, DP(c, di_cls_b(c)), c->logits + r0, nB, c->dC[c->Ld] * 16, s);
 }
 
 // Backward through the Discriminator from d(logit).  want_wgrad: fill the D gradient arena
-// (D step); want_dimage: continue to d(pre-tanh image) (G step).
-static void d_backward_pass(siggan_ctx* c, const float* x0, int n0, const float* x1, int Bd, bool dropout,
-                            bool want_wgrad, bool want_dimage, hipStream_t s) {
+// (D step); want_dimage: continue to d(pre-tanh image) (G step).  The chain of input-gradients
+// runs on lane m; each block's weight gradient (lane a) and bias gradient (lane b) only need that
+// block's d(pre-activation) and run beside the rest of the chain.
+static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, const float* x1, int Bd, bool dropout,
+                            bool want_wgrad, bool want_dimage) {
     const float slope = c->cfg.leaky_slope;
-    const int L = c->Ld;
-    launch_cls_bwd(c->dlogit, c->wcp, c->d_a[L], dropout ? c->d_noise[L] : nullptr, slope, c->d_dv[L], Bd, c->dC[L], s);
-    if (want_wgrad) launch_cls_wgrad(c->dlogit, c->d_a[L], DG(c, di_cls_w(c)), DG(c, di_cls_b(c)), Bd, c->dC[L], s);
-    for (int l = L; l >= 2; --l) {
+    const int Ld = c->Ld;
+    launch_cls_bwd(c->dlogit, c->wcp, c->d_a[Ld], dropout ? c->d_noise[Ld] : nullptr, slope, c->d_dv[Ld], Bd, c->dC[Ld], L.m);
+    if (want_wgrad) {
+        L.fork(L.b);
+        launch_cls_wgrad(c->dlogit, c->d_a[Ld], DG(c, di_cls_w(c)), DG(c, di_cls_b(c)), Bd, c->dC[Ld], L.b);
+    }
+    for (int l = Ld; l >= 2; --l) {
         const int Ho = c->S >> l, Hi = 2 * Ho, Co = c->dC[l], Ci = c->dC[l - 1];
         if (want_wgrad) {
+            L.fork(L.a); L.fork(L.b);                      // d_dv[l] is complete on m here
             WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
             w.S = c->d_dv[l]; w.L = c->d_a[l - 1]; w.slab = c->slab; w.B = Bd; w.Cs = Co; w.Cl = Ci;
             w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
             const int max_splits = (int)(c->slab_floats / ((int64_t)Co * 16 * Ci));
-            const int ns = launch_wgrad(w, max_splits, s);
-            launch_wgrad_reduce(c->slab, DG(c, di_w(l)), ns, Co, Ci, s);
-            launch_colsum(c->d_dv[l], (int64_t)Bd * Ho * Ho, Co, DG(c, di_b(l)), c->partial, s);
+            const int ns = launch_wgrad(w, max_splits, L.a);
+            launch_wgrad_reduce(c->slab, DG(c, di_w(l)), ns, Co, Ci, L.a);
+            launch_colsum(c->d_dv[l], (int64_t)Bd * Ho * Ho, Co, DG(c, di_b(l)), c->partial_b, L.b);
         }
         // input gradient ("up" form): contract Cout, produce Cin at (Hi x Hi); fused leaky'/dropout of block l-1
-        GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
+        GConvArgs a = gconv_args(c);
         a.in = c->d_dv[l]; a.wp = c->d_up[l]; a.out = c->d_dv[l - 1];
         a.B = Bd; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
         a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 1; a.M = Bd * Ho * Ho;
         a.epi = EPI_LRELU_BWD; a.aref = c->d_a[l - 1]; a.noise = dropout ? c->d_noise[l - 1] : nullptr; a.slope = slope;
-        launch_gconv(a, s);
+        launch_gconv(a, L.m);
     }
-    if (want_wgrad)
-        launch_conv1_wgrad(c->d_dv[1], x0, n0, x1, DG(c, di_w(1)), DG(c, di_b(1)), c->partial, Bd, c->S, c->dC[1], s);
+    if (want_wgrad) {
+        L.fork(L.b);
+        launch_conv1_wgrad(c->d_dv[1], x0, n0, x1, DG(c, di_w(1)), DG(c, di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
+        L.join(L.a); L.join(L.b);
+    }
     if (want_dimage)
-        launch_conv1_dgrad_tanh(c->d_dv[1], DP(c, di_w(1)), x0, c->dpre, Bd, c->S, c->dC[1], s);
+        launch_conv1_dgrad_tanh(c->d_dv[1], DP(c, di_w(1)), x0, c->dpre, Bd, c->S, c->dC[1], L.m);
 }
 
-// Backward through the Generator from d(pre-tanh) in c->dpre; fills the G gradient arena.
-static void g_backward_pass(siggan_ctx* c, const float* z, int B, hipStream_t s) {
+// Backward through the Generator from d(pre-tanh) in c->dpre; fills the G gradient arena.  Lane m:
+// BatchNorm backward and the input-gradient chain; lane a: the weight gradients.
+static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     const int Lg = c->Lg, S = c->S;
-    launch_final_wgrad(c->dpre, c->g_a[Lg], GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), c->partial, B, S, c->gC[Lg], s);
-    launch_final_dgrad(c->dpre, GP(c, gi_fin_w(c)), c->g_da[Lg], B, S, c->gC[Lg], s);
+    L.fork(L.b);
+    launch_final_wgrad(c->dpre, c->g_a[Lg], GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), c->partial_b, B, S, c->gC[Lg], L.b);
+    launch_final_dgrad(c->dpre, GP(c, gi_fin_w(c)), c->g_da[Lg], B, S, c->gC[Lg], L.m);
     for (int l = Lg; l >= 1; --l) {
         const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
         const int64_t R = (int64_t)B * Ho * Ho;
-        launch_bn_bwd(c->g_da[l], c->g_y[l], c->g_a[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, s);
+        launch_bn_bwd(c->g_da[l], c->g_y[l], c->g_a[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m);
+        L.fork(L.a);                                       // dy[l] is complete on m here
         // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
         WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
         w.S = c->g_a[l - 1]; w.L = c->g_da[l]; w.slab = c->slab; w.B = B; w.Cs = Ci; w.Cl = Co;
         w.lgHs = ilog2i(Hi); w.lgWs = w.lgHs; w.lgCl = ilog2i(Co); w.K = B * Hi * Hi;
         const int max_splits = (int)(c->slab_floats / ((int64_t)Ci * 16 * Co));
-        const int ns = launch_wgrad(w, max_splits, s);
-        launch_wgrad_reduce(c->slab, GG(c, gi_up_w(l)), ns, Ci, Co, s);
+        const int ns = launch_wgrad(w, max_splits, L.a);
+        launch_wgrad_reduce(c->slab, GG(c, gi_up_w(l)), ns, Ci, Co, L.a);
         // input gradient ("down" form): out = Cin at Hi, contract Cout over 16 taps
-        GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
+        GConvArgs a = gconv_args(c);
         a.in = c->g_da[l]; a.wp = c->g_dn[l]; a.out = c->g_da[l - 1];
         a.B = B; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
-        launch_gconv(a, s);
+        launch_gconv(a, L.m);
     }
     launch_bn_bwd(c->g_da[0], c->fc_y, c->g_a[0], B, c->F, c->g_bn[0], c->partial, GG(c, gi_bn0_w()), GG(c, gi_bn0_b()),
-                  c->gC[0], s);
-    launch_fc_wgrad(c->g_da[0], z, GG(c, gi_fc_w()), GG(c, gi_fc_b()), B, c->latent, c->gC[0], s);
+                  c->gC[0], L.m);
+    launch_fc_wgrad(c->g_da[0], z, GG(c, gi_fc_w()), GG(c, gi_fc_b()), B, c->latent, c->gC[0], L.m);
+    L.join(L.a); L.join(L.b);
 }
 
 static void make_noise(siggan_ctx* c, const float* masks, int B, int passes, hipStream_t s) {
@@ -442,6 +524,117 @@ static void make_noise(siggan_ctx* c, const float* masks, int B, int passes, hip
     }
 }
 
+static int check_hyper(const siggan_hyper* hp) {
+    if (!hp) return fail(SIGGAN_E_INVALID, "null hyper-parameters");
+    if (!(hp->lr >= 0.0) || !(hp->beta1 >= 0.0 && hp->beta1 < 1.0) || !(hp->beta2 >= 0.0 && hp->beta2 < 1.0) || !(hp->eps >= 0.0))
+        return fail(SIGGAN_E_INVALID, "invalid Adam hyper-parameters");
+    return SIGGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// the four step phases (inputs already staged in the workspace: c->real_stage, c->z, c->mask_stage)
+// ------------------------------------------------------------------------------------------
+static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
+    const int B = k.B;
+    const bool drop = c->cfg.dropout > 0.f;
+    launch_tick(c->dev, L.m);
+    L.fork(L.a);                                                     // lane a: D's packs, dropout tables, D(real)
+    repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
+    if (drop) make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, 2, L.a);
+    d_forward_rows(c, c->real_stage, 0, B, drop, L.a, c->slab_k2);   // D(real) beside the Generator (train...py:309)
+    if (!k.has_z) launch_randn(c->z, (int64_t)B * c->latent, c->dev, 1, L.m);
+    g_forward_pass(c, c->z, B, false, c->img, L.m);                  // G.eval(), no grad (train...py:314-315)
+    L.join(L.a);
+    d_forward_rows(c, c->img, B, B, drop, L.m, c->slab_k);           // D(fake) into rows [B, 2B)
+    launch_bce(c->logits, 2 * B, B, k.ls, 0.f, c->probs, c->dlogit, c->metrics, 0, L.m);
+    d_backward_pass(c, L, c->real_stage, B, c->img, 2 * B, drop, true, false);
+}
+
+static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
+    const int B = k.B;
+    launch_tick(c->dev, L.m);
+    L.fork(L.a);
+    repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
+    if (!k.has_z) launch_randn(c->z, (int64_t)B * c->latent, c->dev, 2, L.m);
+    g_forward_pass(c, c->z, B, true, c->img, L.m);                   // G.train(): BN batch stats (train...py:349)
+    L.join(L.a);
+    d_forward_rows(c, c->img, 0, B, false, L.m, c->slab_k);          // D.eval(): dropout off (train...py:350)
+    launch_bce(c->logits, B, B, 1.0f, 1.0f, c->probs, c->dlogit, c->metrics, 1, L.m);
+    d_backward_pass(c, L, c->img, B, c->img, B, false, false, true); // through D into the image; no D weight grads
+    g_backward_pass(c, L, c->z, B);
+}
+
+static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
+    const int which = k.phase == 2 ? 1 : 0;                          // phase 2 = D apply, 3 = G apply
+    float* p = which == 0 ? c->st.g_params : c->st.d_params;
+    float* g = which == 0 ? c->st.g_grads : c->st.d_grads;
+    float* m = which == 0 ? c->st.g_exp_avg : c->st.d_exp_avg;
+    float* v = which == 0 ? c->st.g_exp_avg_sq : c->st.d_exp_avg_sq;
+    float* steps = which == 0 ? c->st.g_adam_steps : c->st.d_adam_steps;
+    const int64_t n = which == 0 ? c->g_total : c->d_total;
+    const int nt = (int)(which == 0 ? c->g_off.size() : c->d_off.size());
+    const bool clip = k.clip > 0.f;
+    if (clip) launch_grad_sumsq(g, n, c->dev, c->partial, L.m);
+    launch_adam_prepare(c->dev, steps, nt, k.lr, k.beta1, k.beta2, k.gs, k.clip,
+                        c->metrics + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), L.m);
+    launch_adam(p, g, m, v, n, c->dev, k.beta1, k.beta2, k.eps, (clip || k.gs != 1.0f) ? 1 : 0, L.m);
+}
+
+static void run_phase_body(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
+    if (k.phase == 0) phase_d_grads(c, L, k);
+    else if (k.phase == 1) phase_g_grads(c, L, k);
+    else phase_apply(c, L, k);
+}
+
+// Enqueue one phase behind everything on the caller's stream u.  Eager: directly on u (side lanes
+// forked from it).  Graph mode: the phase is captured once per distinct key on the library's own
+// main lane (a caller stream may be the legacy default stream, which cannot be captured) and replayed.
+static int run_phase(siggan_ctx* c, const PhaseKey& k, hipStream_t u) {
+    const bool overlap = (c->mode & SIGGAN_MODE_OVERLAP) != 0;
+    const bool graph = (c->mode & SIGGAN_MODE_GRAPH) != 0 && g_prof == nullptr;
+    if (!graph) {
+        Lanes L{c, u, overlap ? c->s_a : u, overlap ? c->s_b : u};
+        run_phase_body(c, L, k);
+        LAUNCHCHK();
+        return SIGGAN_OK;
+    }
+    hipGraphExec_t exec = nullptr;
+    for (auto& e : c->graphs)
+        if (e.first == k) { exec = e.second; break; }
+    if (!exec) {
+        Lanes L{c, c->s_m, overlap ? c->s_a : c->s_m, overlap ? c->s_b : c->s_m};
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(c->s_m, hipStreamCaptureModeRelaxed));
+        run_phase_body(c, L, k);
+        hipError_t e1 = hipStreamEndCapture(c->s_m, &g);
+        if (e1 != hipSuccess || !g) return fail(SIGGAN_E_HIP, "stream capture failed: %s", hipGetErrorString(e1));
+        hipError_t e2 = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e2 != hipSuccess) return fail(SIGGAN_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2));
+        if (c->graphs.size() >= 64) { (void)hipGraphExecDestroy(c->graphs.front().second); c->graphs.erase(c->graphs.begin()); }
+        c->graphs.emplace_back(k, exec);
+    }
+    hipEvent_t e_in = c->ev_bridge[0], e_out = c->ev_bridge[1];
+    HIPCHK(hipEventRecord(e_in, u));
+    HIPCHK(hipStreamWaitEvent(c->s_m, e_in, 0));
+    HIPCHK(hipGraphLaunch(exec, c->s_m));
+    HIPCHK(hipEventRecord(e_out, c->s_m));
+    HIPCHK(hipStreamWaitEvent(u, e_out, 0));
+    return SIGGAN_OK;
+}
+
+static PhaseKey make_key(siggan_ctx* c, int phase, int B, bool has_z, bool has_masks, const siggan_hyper* hp) {
+    PhaseKey k; memset(&k, 0, sizeof k);
+    k.phase = phase; k.B = B; k.has_z = has_z; k.has_masks = has_masks;
+    if (phase <= 1) { k.g_dirty = c->g_dirty; k.d_dirty = c->d_dirty; k.ls = hp->label_smoothing; }
+    else {
+        k.lr = hp->lr; k.beta1 = hp->beta1; k.beta2 = hp->beta2; k.eps = hp->eps;
+        k.clip = hp->clip_max_norm > 0.f ? hp->clip_max_norm : 0.f;
+        k.gs = hp->grad_scale > 0.f ? hp->grad_scale : 1.0f;
+    }
+    return k;
+}
+
 static int finish_metrics(siggan_ctx* c, float* metrics_dev, float* metrics_host, hipStream_t s) {
     if (metrics_dev) HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (metrics_host) {
@@ -451,44 +644,25 @@ static int finish_metrics(siggan_ctx* c, float* metrics_dev, float* metrics_host
     return SIGGAN_OK;
 }
 
-static int check_hyper(const siggan_hyper* hp) {
-    if (!hp) return fail(SIGGAN_E_INVALID, "null hyper-parameters");
-    if (!(hp->lr >= 0.0) || !(hp->beta1 >= 0.0 && hp->beta1 < 1.0) || !(hp->beta2 >= 0.0 && hp->beta2 < 1.0) || !(hp->eps >= 0.0))
-        return fail(SIGGAN_E_INVALID, "invalid Adam hyper-parameters");
-    return SIGGAN_OK;
-}
-
-static int apply_adam(siggan_ctx* c, int which, const siggan_hyper* hp, hipStream_t s) {
-    float* p = which == 0 ? c->st.g_params : c->st.d_params;
-    float* g = which == 0 ? c->st.g_grads : c->st.d_grads;
-    float* m = which == 0 ? c->st.g_exp_avg : c->st.d_exp_avg;
-    float* v = which == 0 ? c->st.g_exp_avg_sq : c->st.d_exp_avg_sq;
-    float* steps = which == 0 ? c->st.g_adam_steps : c->st.d_adam_steps;
-    const int64_t n = which == 0 ? c->g_total : c->d_total;
-    const int nt = (int)(which == 0 ? c->g_off.size() : c->d_off.size());
-    if (!g || !m || !v || !steps) return fail(SIGGAN_E_STATE, "gradient / Adam arenas were not bound");
-    const bool clip = hp->clip_max_norm > 0.f;
-    const float gs = hp->grad_scale > 0.f ? hp->grad_scale : 1.0f;
-    if (clip) launch_grad_sumsq(g, n, c->dev, c->partial, s);
-    launch_adam_prepare(c->dev, steps, nt, hp->lr, hp->beta1, hp->beta2, gs, hp->clip_max_norm,
-                        c->metrics + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), s);
-    launch_adam(p, g, m, v, n, c->dev, hp->beta1, hp->beta2, hp->eps, (clip || gs != 1.0f) ? 1 : 0, s);
-    if (which == 0) c->g_dirty = true; else c->d_dirty = true;
-    LAUNCHCHK();
-    return SIGGAN_OK;
-}
-
 // ------------------------------------------------------------------------------------------
 // public passes
 // ------------------------------------------------------------------------------------------
+extern "C" int siggan_set_mode(siggan_ctx* c, int32_t mode) {
+    if (!c) return fail(SIGGAN_E_INVALID, "null context");
+    c->mode = mode;
+    return SIGGAN_OK;
+}
+
 extern "C" int siggan_g_forward(siggan_ctx* c, const float* z_dev, int32_t batch, int32_t training, float* images_dev,
                                 void* stream) {
     int rc = check_call(c, batch);
     if (rc) return rc;
     if (!z_dev || !images_dev) return fail(SIGGAN_E_INVALID, "null tensor");
     hipStream_t s = (hipStream_t)stream;
-    repack(c, s);
+    repack(c, s, s, c->g_dirty, c->d_dirty);
+    c->g_dirty = c->d_dirty = false;
     g_forward_pass(c, z_dev, batch, training != 0, images_dev, s);
+    if (training) c->g_dirty = true;   // running statistics moved: the eval-mode tables are stale
     LAUNCHCHK();
     return SIGGAN_OK;
 }
@@ -499,10 +673,11 @@ extern "C" int siggan_d_forward(siggan_ctx* c, const float* x_dev, int32_t batch
     if (rc) return rc;
     if (!x_dev || (!probs_dev && !features_dev)) return fail(SIGGAN_E_INVALID, "null tensor");
     hipStream_t s = (hipStream_t)stream;
-    repack(c, s);
+    repack(c, s, s, c->g_dirty, c->d_dirty);
+    c->g_dirty = c->d_dirty = false;
     const bool drop = training != 0 && c->cfg.dropout > 0.f;
     if (drop) { if (!masks_dev) launch_tick(c->dev, s); make_noise(c, masks_dev, batch, 1, s); }
-    d_forward_pass(c, x_dev, batch, x_dev, batch, drop, s);
+    d_forward_rows(c, x_dev, 0, batch, drop, s, c->slab_k);
     if (probs_dev) launch_bce(c->logits, batch, batch, 0.f, 0.f, probs_dev, nullptr, nullptr, 0, s);
     if (features_dev) launch_cls_features(c->d_a[c->Ld], features_dev, batch, c->dC[c->Ld], s);
     LAUNCHCHK();
@@ -518,31 +693,41 @@ extern "C" int siggan_d_grads(siggan_ctx* c, const float* real_dev, int32_t batc
     if (!c->st.d_grads) return fail(SIGGAN_E_STATE, "gradient arena was not bound");
     hipStream_t s = (hipStream_t)stream;
     const int B = batch;
-    repack(c, s);
-    launch_tick(c->dev, s);
-    const float* z = z_dev;
-    if (!z) { launch_randn(c->z, (int64_t)B * c->latent, c->dev, 1, s); z = c->z; }
-    const bool drop = c->cfg.dropout > 0.f;
-    if (drop) make_noise(c, masks_dev, B, 2, s);
-    g_forward_pass(c, z, B, false, c->img, s);                       // G.eval(), no grad (train...py:314-315)
-    d_forward_pass(c, real_dev, B, c->img, 2 * B, drop, s);          // D(real) and D(fake) as one 2B batch
-    launch_bce(c->logits, 2 * B, B, hp->label_smoothing, 0.f, c->probs, c->dlogit, c->metrics, 0, s);
-    d_backward_pass(c, real_dev, B, c->img, 2 * B, drop, true, false, s);
-    LAUNCHCHK();
+    const size_t img_bytes = (size_t)B * c->S * c->S * sizeof(float);
+    // stage the caller's tensors into fixed workspace slots (captured phases must see fixed addresses)
+    if (real_dev != c->real_stage) HIPCHK(hipMemcpyAsync(c->real_stage, real_dev, img_bytes, hipMemcpyDeviceToDevice, s));
+    if (z_dev && z_dev != c->z) HIPCHK(hipMemcpyAsync(c->z, z_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
+    int64_t sumC = 0;
+    for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l];
+    if (masks_dev) HIPCHK(hipMemcpyAsync(c->mask_stage, masks_dev, (size_t)2 * B * sumC * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const PhaseKey k = make_key(c, 0, B, z_dev != nullptr, masks_dev != nullptr, hp);
+    if ((rc = run_phase(c, k, s))) return rc;
+    c->g_dirty = c->d_dirty = false;
     c->pending = 1;
     if (metrics_dev) HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, s));
     return SIGGAN_OK;
 }
 
-extern "C" int siggan_d_apply(siggan_ctx* c, const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
+static int apply_common(siggan_ctx* c, int which, const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
     int rc = check_call(c, 1);
     if (rc) return rc;
     if ((rc = check_hyper(hp))) return rc;
-    if (c->pending != 1) return fail(SIGGAN_E_STATE, "siggan_d_apply without a preceding siggan_d_grads");
+    if (c->pending != (which == 1 ? 1 : 2))
+        return fail(SIGGAN_E_STATE, "siggan_%c_apply without a preceding siggan_%c_grads", which ? 'd' : 'g', which ? 'd' : 'g');
+    const float* need[] = {which ? c->st.d_grads : c->st.g_grads, which ? c->st.d_exp_avg : c->st.g_exp_avg,
+                           which ? c->st.d_exp_avg_sq : c->st.g_exp_avg_sq, which ? c->st.d_adam_steps : c->st.g_adam_steps};
+    for (const float* p : need)
+        if (!p) return fail(SIGGAN_E_STATE, "gradient / Adam arenas were not bound");
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = apply_adam(c, 1, hp, s))) return rc;
+    const PhaseKey k = make_key(c, which == 1 ? 2 : 3, 0, false, false, hp);
+    if ((rc = run_phase(c, k, s))) return rc;
+    if (which == 0) c->g_dirty = true; else c->d_dirty = true;
     c->pending = 0;
     return finish_metrics(c, metrics_dev, metrics_host, s);
+}
+
+extern "C" int siggan_d_apply(siggan_ctx* c, const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
+    return apply_common(c, 1, hp, metrics_dev, metrics_host, stream);
 }
 
 extern "C" int siggan_d_step(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
@@ -560,34 +745,18 @@ extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, 
     if (!c->st.g_grads) return fail(SIGGAN_E_STATE, "gradient arena was not bound");
     hipStream_t s = (hipStream_t)stream;
     const int B = batch;
-    repack(c, s);
-    launch_tick(c->dev, s);
-    const float* z = z_dev;
-    if (!z) { launch_randn(c->z, (int64_t)B * c->latent, c->dev, 2, s); z = c->z; }
-    else if (z != c->z) {
-        HIPCHK(hipMemcpyAsync(c->z, z, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
-        z = c->z;
-    }
-    g_forward_pass(c, z, B, true, c->img, s);                        // G.train(): BN batch stats (train...py:349)
-    d_forward_pass(c, c->img, B, c->img, B, false, s);               // D.eval(): dropout off (train...py:350)
-    launch_bce(c->logits, B, B, 1.0f, 1.0f, c->probs, c->dlogit, c->metrics, 1, s);
-    d_backward_pass(c, c->img, B, c->img, B, false, false, true, s); // through D into the image; no D weight grads
-    g_backward_pass(c, z, B, s);
-    LAUNCHCHK();
+    if (z_dev && z_dev != c->z) HIPCHK(hipMemcpyAsync(c->z, z_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const PhaseKey k = make_key(c, 1, B, z_dev != nullptr, false, hp);
+    if ((rc = run_phase(c, k, s))) return rc;
+    c->d_dirty = false;
+    c->g_dirty = true;                 // the training forward moved the BatchNorm running statistics
     c->pending = 2;
     if (metrics_dev) HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, s));
     return SIGGAN_OK;
 }
 
 extern "C" int siggan_g_apply(siggan_ctx* c, const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
-    int rc = check_call(c, 1);
-    if (rc) return rc;
-    if ((rc = check_hyper(hp))) return rc;
-    if (c->pending != 2) return fail(SIGGAN_E_STATE, "siggan_g_apply without a preceding siggan_g_grads");
-    hipStream_t s = (hipStream_t)stream;
-    if ((rc = apply_adam(c, 0, hp, s))) return rc;
-    c->pending = 0;
-    return finish_metrics(c, metrics_dev, metrics_host, s);
+    return apply_common(c, 0, hp, metrics_dev, metrics_host, stream);
 }
 
 extern "C" int siggan_g_step(siggan_ctx* c, int32_t batch, const float* z_dev, const siggan_hyper* hp, float* metrics_dev,
@@ -612,7 +781,7 @@ extern "C" int siggan_op_conv4x4s2(siggan_ctx* c, int32_t form, const float* in_
     if (form == 0 && h_in < 2) return fail(SIGGAN_E_INVALID, "down form needs h_in >= 2");
     HIPCHK(hipSetDevice(c->cfg.device));
     hipStream_t s = (hipStream_t)stream;
-    GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab; a.slab_floats = c->slab_floats; a.zeros = c->zeros;
+    GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab_k; a.slab_floats = c->slab_k_floats; a.zeros = c->zeros;
     a.in = in_dev; a.wp = c->op_pack; a.out = out_dev; a.B = batch; a.Hi = h_in; a.Wi = h_in; a.Ci = c_in; a.Co = c_out;
     a.form = form; a.epi = EPI_RAW;
     if (form == 0) {

@@ -132,6 +132,10 @@ class Engine:
         """Call after writing parameters / BN buffers from outside (load_state_dict, init)."""
         _lib.check(self.lib.siggan_params_changed(self._h))
 
+    def set_mode(self, graph=False, overlap=True):
+        """Step-phase execution mode: hipGraph replay and/or side-stream overlap (default: overlap only)."""
+        _lib.check(self.lib.siggan_set_mode(self._h, (1 if graph else 0) | (2 if overlap else 0)))
+
     def seed(self, seed, offset=0):
         _lib.check(self.lib.siggan_seed(self._h, int(seed), int(offset)))
 

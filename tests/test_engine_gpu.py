@@ -211,3 +211,32 @@ def test_three_step_sequence(size, latent, batch):
                      gm["g_loss"], gm["g_fake_mean"]])
     assert_close(np.array(rows), f["seq3/metrics"], 1e-3, 1e-4, "3-step metrics vs golden")
     eng.close()
+
+
+def test_execution_modes_are_bitwise_identical():
+    """hipGraph replay and side-stream overlap only change scheduling: with injected noise and
+    masks the four mode combinations must give bit-identical parameters, moments and metrics,
+    also on the replayed (second and third) steps."""
+    from hipcommon import cuda, make_engine
+    size, latent, batch = 64, 100, 16
+    real = cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"])))
+    masks = [torch.from_numpy(m) for m in I.gen_masks(batch, d_chans(size) * 2, 3)]
+    ref = None
+    for graph, overlap in ((False, False), (True, True), (True, False), (False, True)):
+        eng = make_engine(size, latent, batch, warm=True)
+        eng.set_mode(graph=graph, overlap=overlap)
+        mets = []
+        for s in range(3):
+            z1 = cuda(torch.from_numpy(I.gen_z(batch, latent, 50 + s)))
+            z2 = cuda(torch.from_numpy(I.gen_z(batch, latent, 60 + s)))
+            mets.append(eng.d_step(real, z1, masks, clip=0.5))
+            mets.append(eng.g_step(batch, z2, clip=0.5))
+        state = [t.clone() for t in (eng.g_params, eng.d_params, eng.g_exp_avg_sq, eng.d_exp_avg, eng.g_bn_mean, eng.g_bn_var,
+                                     eng.g_adam_steps, eng.g_bn_batches)]
+        eng.close()
+        if ref is None:
+            ref = (state, mets)
+        else:
+            for a, b in zip(ref[0], state):
+                assert torch.equal(a, b), f"mode graph={graph} overlap={overlap} changed the result"
+            assert mets == ref[1]
