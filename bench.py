@@ -14,7 +14,9 @@ gradient buckets are all-reduced over RCCL between grads and apply: weak scaling
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant MFMA kernel: algorithmic FLOPs per launch / its mean launch duration
                   measured with HIP events on the launch stream over a second, instrumented pass of
-                  the same K steps (the timed pass itself carries no instrumentation)
+                  the same K steps, run one kernel at a time (the timed pass carries no instrumentation
+                  and overlaps independent kernels on side streams; `--serialize` turns that off for the
+                  whole run, which is how the rocprofv3 summaries under profiles/ are taken)
   cpu_baseline -- the oracle's same step (torch CPU, fp32) timed on the host cores (rank 0, N = 1)
 """
 import argparse
@@ -67,6 +69,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented pass")
+    ap.add_argument("--serialize", action="store_true",
+                    help="run every pass with side-lane overlap OFF (one kernel at a time): the mode the roofline "
+                         "pass always uses, and the one to profile with rocprofv3 so per-kernel durations agree")
     args = ap.parse_args()
 
     import torch
@@ -87,6 +92,8 @@ def main():
 
     eng = Engine(latent_dim=LATENT, image_size=SIZE, max_batch=BATCH, device=str(dev), seed=2 + rank)
     eng.init_reference(seed=0)                                  # identical initial weights on every rank
+    if args.serialize:
+        eng.set_mode(graph=False, overlap=False)
     dp = DataParallelStep(eng)
     dp.sync_initial_state()
     gen = torch.Generator(device="cpu").manual_seed(1 + rank)
@@ -115,11 +122,15 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
+        # one kernel at a time: a launch's event-bracketed time is then the kernel's own duration
+        # (with overlap on, two MFMA kernels share the chip and each looks proportionally longer)
+        eng.set_mode(graph=False, overlap=False)
         eng.prof_enable(True)
         for _ in range(args.steps):
             dp.step(real) if world == 1 else (eng.d_step(real, sync=False), eng.g_step(BATCH, sync=False))
         recs = eng.prof_read()
         eng.prof_enable(False)
+        eng.set_mode(graph=False, overlap=not args.serialize)
         top = max(recs, key=lambda r: r["ms"])
         ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
         fam_ms, fam_fl = sum(r["ms"] for r in recs), sum(r["flops"] for r in recs)

@@ -159,6 +159,14 @@ int siggan_g_step(siggan_ctx *ctx, int32_t batch, const float *z_dev, const sigg
  * hp->grad_scale, clips and runs Adam. */
 int siggan_d_grads(siggan_ctx *ctx, const float *real_dev, int32_t batch, const float *z_dev,
                    const float *masks_dev, const siggan_hyper *hp, float *metrics_dev, void *stream);
+/* siggan_d_grads that ALSO enqueues the following G step's training forward (z: zg_dev, or the library
+ * RNG when NULL) on its own lane beside the D step's backward -- that forward depends on nothing the D
+ * step changes (train_vanilla_gan_signatures.py:349-357).  Must be followed by siggan_d_apply and then
+ * siggan_g_grads(batch, z_dev = NULL), which picks the forward up.  Results are bit-identical to the
+ * un-pipelined calls; without SIGGAN_MODE_OVERLAP it degrades to siggan_d_grads. */
+int siggan_step_begin(siggan_ctx *ctx, const float *real_dev, int32_t batch, const float *z_dev,
+                      const float *masks_dev, const float *zg_dev, const siggan_hyper *hp,
+                      float *metrics_dev, void *stream);
 int siggan_d_apply(siggan_ctx *ctx, const siggan_hyper *hp, float *metrics_dev, float *metrics_host,
                    void *stream);
 int siggan_g_grads(siggan_ctx *ctx, int32_t batch, const float *z_dev, const siggan_hyper *hp,

@@ -43,12 +43,12 @@ static const int MAXL = 6;
 static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 struct PhaseKey {
-    int phase, B, has_z, has_masks, g_dirty, d_dirty;
+    int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg;
     double lr, beta1, beta2, eps;
     float ls, clip, gs;
     bool operator==(const PhaseKey& o) const {
         return phase == o.phase && B == o.B && has_z == o.has_z && has_masks == o.has_masks && g_dirty == o.g_dirty &&
-               d_dirty == o.d_dirty && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
+               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
                clip == o.clip && gs == o.gs;
     }
 };
@@ -73,7 +73,7 @@ struct siggan_ctx {
     float *d_a[MAXL + 1], *d_dv[MAXL + 1], *d_noise[MAXL + 1];
     float *logits, *probs, *dlogit;
     float *g_up[MAXL + 1], *g_dn[MAXL + 1], *d_dn[MAXL + 1], *d_up[MAXL + 1], *wcp;
-    float *slab, *slab_k, *slab_k2, *partial, *partial_b, *metrics, *op_pack, *zeros, *wfc_t, *real_stage, *mask_stage;
+    float *slab, *slab_k, *slab_k2, *partial, *partial_b, *partial_c, *z_g, *img_g, *metrics, *op_pack, *zeros, *wfc_t, *real_stage, *mask_stage;
     int64_t slab_floats, slab_k_floats;
     DevState* dev;
     // last *_grads call (for *_apply)
@@ -81,7 +81,10 @@ struct siggan_ctx {
     // lanes / graphs
     static constexpr int NEV = 96;
     int mode;
-    hipStream_t s_m, s_a, s_b;
+    hipStream_t s_m, s_a, s_b, s_c;
+    hipEvent_t ev_gfwd;
+    int zg_stash;        // batch of an explicit G-step z handed to siggan_step_begin when the forward was not pipelined
+    int g_fwd_pending;   // batch of a Generator training forward already enqueued by siggan_step_begin (0: none)
     hipEvent_t ev[NEV], ev_bridge[2];
     int evi;
     std::vector<std::pair<PhaseKey, hipGraphExec_t>> graphs;
@@ -204,6 +207,9 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->slab_k2, c->slab_k_floats);
         carve(&c->partial, (int64_t)2 << 20);
         carve(&c->partial_b, (int64_t)2 << 20);
+        carve(&c->partial_c, (int64_t)2 << 20);
+        carve(&c->z_g, Bm * c->latent);
+        carve(&c->img_g, Bm * c->S * c->S);
         carve(&c->real_stage, Bm * c->S * c->S);
         { int64_t sumC = 0; for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l]; carve(&c->mask_stage, 2 * Bm * sumC); }
         carve(&c->metrics, SIGGAN_M_COUNT);
@@ -230,6 +236,10 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->s_m, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->s_a, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->s_b, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->s_c, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_gfwd, hipEventDisableTiming));
+    c->g_fwd_pending = 0;
+    c->zg_stash = 0;
     for (int i = 0; i < siggan_ctx::NEV; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_bridge[i], hipEventDisableTiming));
     *out = c;
@@ -246,6 +256,8 @@ extern "C" int siggan_destroy(siggan_ctx* c) {
     if (c->s_m) (void)hipStreamDestroy(c->s_m);
     if (c->s_a) (void)hipStreamDestroy(c->s_a);
     if (c->s_b) (void)hipStreamDestroy(c->s_b);
+    if (c->s_c) (void)hipStreamDestroy(c->s_c);
+    if (c->ev_gfwd) (void)hipEventDestroy(c->ev_gfwd);
     if (c->ws) (void)hipFree(c->ws);
     delete c;
     return SIGGAN_OK;
@@ -382,16 +394,19 @@ static GConvArgs gconv_args(siggan_ctx* c) {
 
 // Generator.forward (generator_vanilla_gan.py:189-209).  training: BN batch stats (+ running
 // update) and raw pre-BN outputs kept for the backward pass; eval: BN folded into the epilogue.
-static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s) {
+static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s,
+                           float* partial = nullptr, float* slab_k = nullptr) {
+    if (!partial) partial = c->partial;
     launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s);
     if (training)
         launch_bn_train_stats(c->fc_y, B, c->F, GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), c->st.g_bn_running_mean,
-                              c->st.g_bn_running_var, c->st.g_bn_batches, c->g_bn[0], c->partial, c->gC[0], BN_MOMENTUM,
+                              c->st.g_bn_running_var, c->st.g_bn_batches, c->g_bn[0], partial, c->gC[0], BN_MOMENTUM,
                               BN_EPS, s);
     launch_bn_relu(c->fc_y, c->g_a[0], B, c->F, training ? c->g_bn[0] : c->g_bne[0], s);
     for (int l = 1; l <= c->Lg; ++l) {
         const int Hi = 4 << (l - 1), Ci = c->gC[l - 1], Co = c->gC[l];
         GConvArgs a = gconv_args(c);
+        if (slab_k) a.slab = slab_k;
         a.in = c->g_a[l - 1]; a.wp = c->g_up[l]; a.B = B; a.Hi = Hi; a.Wi = Hi; a.Ci = Ci; a.Co = Co;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = 2 * Hi; a.Wo = 2 * Hi; a.form = 1; a.M = B * Hi * Hi;
         const int C = Co;
@@ -401,7 +416,7 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
             launch_gconv(a, s);
             const int64_t R = (int64_t)B * 4 * Hi * Hi;
             launch_bn_train_stats(c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
-                                  c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], c->partial, 0,
+                                  c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
                                   BN_MOMENTUM, BN_EPS, s);
             launch_bn_relu(c->g_y[l], c->g_a[l], R, C, c->g_bn[l], s);
         } else {
@@ -545,6 +560,15 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     if (!k.has_z) launch_randn(c->z, (int64_t)B * c->latent, c->dev, 1, L.m);
     g_forward_pass(c, c->z, B, false, c->img, L.m);                  // G.eval(), no grad (train...py:314-315)
     L.join(L.a);
+    if (k.spec_g) {
+        // siggan_step_begin: the G step's training forward depends on nothing the D step changes, so it
+        // runs on its own lane beside the D step's backward (after the eval forward above: it moves the
+        // BatchNorm running statistics and reuses the activation buffers; its own image / z / scratch).
+        L.fork(c->s_c);
+        if (!k.has_zg) launch_randn(c->z_g, (int64_t)B * c->latent, c->dev, 2, c->s_c);
+        g_forward_pass(c, c->z_g, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2);
+        (void)hipEventRecord(c->ev_gfwd, c->s_c);
+    }
     d_forward_rows(c, c->img, B, B, drop, L.m, c->slab_k);           // D(fake) into rows [B, 2B)
     launch_bce(c->logits, 2 * B, B, k.ls, 0.f, c->probs, c->dlogit, c->metrics, 0, L.m);
     d_backward_pass(c, L, c->real_stage, B, c->img, 2 * B, drop, true, false);
@@ -552,16 +576,24 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
 
 static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const int B = k.B;
-    launch_tick(c->dev, L.m);
-    L.fork(L.a);
-    repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
-    if (!k.has_z) launch_randn(c->z, (int64_t)B * c->latent, c->dev, 2, L.m);
-    g_forward_pass(c, c->z, B, true, c->img, L.m);                   // G.train(): BN batch stats (train...py:349)
-    L.join(L.a);
-    d_forward_rows(c, c->img, 0, B, false, L.m, c->slab_k);          // D.eval(): dropout off (train...py:350)
+    const float* zg; float* img;
+    if (k.spec_g) {                                                  // forward already enqueued by siggan_step_begin
+        repack(c, L.m, L.m, false, k.d_dirty != 0);
+        (void)hipStreamWaitEvent(L.m, c->ev_gfwd, 0);
+        zg = c->z_g; img = c->img_g;
+    } else {
+        launch_tick(c->dev, L.m);
+        L.fork(L.a);
+        repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
+        if (!k.has_z) launch_randn(c->z, (int64_t)B * c->latent, c->dev, 2, L.m);
+        g_forward_pass(c, c->z, B, true, c->img, L.m);               // G.train(): BN batch stats (train...py:349)
+        L.join(L.a);
+        zg = c->z; img = c->img;
+    }
+    d_forward_rows(c, img, 0, B, false, L.m, c->slab_k);             // D.eval(): dropout off (train...py:350)
     launch_bce(c->logits, B, B, 1.0f, 1.0f, c->probs, c->dlogit, c->metrics, 1, L.m);
-    d_backward_pass(c, L, c->img, B, c->img, B, false, false, true); // through D into the image; no D weight grads
-    g_backward_pass(c, L, c->z, B);
+    d_backward_pass(c, L, img, B, img, B, false, false, true);       // through D into the image; no D weight grads
+    g_backward_pass(c, L, zg, B);
 }
 
 static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
@@ -684,13 +716,16 @@ extern "C" int siggan_d_forward(siggan_ctx* c, const float* x_dev, int32_t batch
     return SIGGAN_OK;
 }
 
-extern "C" int siggan_d_grads(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
-                              const siggan_hyper* hp, float* metrics_dev, void* stream) {
+static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
+                          const siggan_hyper* hp, float* metrics_dev, void* stream, bool spec_g, const float* zg_dev) {
     int rc = check_call(c, batch);
     if (rc) return rc;
     if ((rc = check_hyper(hp))) return rc;
     if (!real_dev) return fail(SIGGAN_E_INVALID, "null real batch");
     if (!c->st.d_grads) return fail(SIGGAN_E_STATE, "gradient arena was not bound");
+    if (c->g_fwd_pending) return fail(SIGGAN_E_STATE, "siggan_step_begin must be followed by siggan_g_grads before the next D step");
+    // the speculative forward needs its own lane: without overlap (or under graph replay) it is skipped
+    if (spec_g && ((c->mode & SIGGAN_MODE_OVERLAP) == 0 || (c->mode & SIGGAN_MODE_GRAPH) != 0 || g_prof != nullptr)) spec_g = false;
     hipStream_t s = (hipStream_t)stream;
     const int B = batch;
     const size_t img_bytes = (size_t)B * c->S * c->S * sizeof(float);
@@ -700,12 +735,26 @@ extern "C" int siggan_d_grads(siggan_ctx* c, const float* real_dev, int32_t batc
     int64_t sumC = 0;
     for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l];
     if (masks_dev) HIPCHK(hipMemcpyAsync(c->mask_stage, masks_dev, (size_t)2 * B * sumC * sizeof(float), hipMemcpyDeviceToDevice, s));
-    const PhaseKey k = make_key(c, 0, B, z_dev != nullptr, masks_dev != nullptr, hp);
+    if (zg_dev) HIPCHK(hipMemcpyAsync(c->z_g, zg_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
+    c->zg_stash = (!spec_g && zg_dev) ? B : 0;
+    PhaseKey k = make_key(c, 0, B, z_dev != nullptr, masks_dev != nullptr, hp);
+    k.spec_g = spec_g; k.has_zg = spec_g && zg_dev != nullptr;
     if ((rc = run_phase(c, k, s))) return rc;
     c->g_dirty = c->d_dirty = false;
+    if (spec_g) { c->g_fwd_pending = B; c->g_dirty = true; }   // running statistics moved
     c->pending = 1;
     if (metrics_dev) HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, s));
     return SIGGAN_OK;
+}
+
+extern "C" int siggan_d_grads(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
+                              const siggan_hyper* hp, float* metrics_dev, void* stream) {
+    return d_grads_common(c, real_dev, batch, z_dev, masks_dev, hp, metrics_dev, stream, false, nullptr);
+}
+
+extern "C" int siggan_step_begin(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
+                                 const float* zg_dev, const siggan_hyper* hp, float* metrics_dev, void* stream) {
+    return d_grads_common(c, real_dev, batch, z_dev, masks_dev, hp, metrics_dev, stream, true, zg_dev);
 }
 
 static int apply_common(siggan_ctx* c, int which, const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
@@ -745,9 +794,16 @@ extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, 
     if (!c->st.g_grads) return fail(SIGGAN_E_STATE, "gradient arena was not bound");
     hipStream_t s = (hipStream_t)stream;
     const int B = batch;
-    if (z_dev && z_dev != c->z) HIPCHK(hipMemcpyAsync(c->z, z_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
-    const PhaseKey k = make_key(c, 1, B, z_dev != nullptr, false, hp);
+    const bool spec = c->g_fwd_pending != 0;
+    if (spec && (c->g_fwd_pending != B || z_dev))
+        return fail(SIGGAN_E_STATE, "siggan_g_grads after siggan_step_begin must use the same batch and no explicit z (pass it to step_begin)");
+    if (!spec && !z_dev && c->zg_stash == B) z_dev = c->z_g;          // z given to a step_begin that could not pipeline
+    c->zg_stash = 0;
+    if (!spec && z_dev && z_dev != c->z) HIPCHK(hipMemcpyAsync(c->z, z_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
+    PhaseKey k = make_key(c, 1, B, z_dev != nullptr, false, hp);
+    k.spec_g = spec;
     if ((rc = run_phase(c, k, s))) return rc;
+    c->g_fwd_pending = 0;
     c->d_dirty = false;
     c->g_dirty = true;                 // the training forward moved the BatchNorm running statistics
     c->pending = 2;

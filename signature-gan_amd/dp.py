@@ -52,10 +52,10 @@ class DataParallelStep:
 
     def step(self, real_local, z_d=None, z_g=None, masks=None, sync=False):
         e, hp, inv = self.e, self.hp, 1.0 / self.world
-        e.d_compute_grads(real_local, z_d, masks, hp["ls"])
+        e.step_begin(real_local, z_d, masks, z_g, hp["ls"])       # D grads + the G step's forward beside them
         allreduce_sum_(e.d_grads)
         dm = e.d_apply(hp["lr_d"], hp["beta1"], hp["beta2"], clip=hp["clip"], grad_scale=inv, sync=sync)
-        e.g_compute_grads(real_local.shape[0], z_g)
+        e.g_compute_grads(real_local.shape[0])
         allreduce_sum_(e.g_grads)
         gm = e.g_apply(hp["lr_g"], hp["beta1"], hp["beta2"], clip=hp["clip"], grad_scale=inv, sync=sync)
         if sync:

@@ -212,6 +212,29 @@ class Engine:
         _lib.check(self.lib.siggan_d_grads(self._h, _ptr(real), b, _ptr(z), _ptr(masks), C.byref(hp), _ptr(self.metrics),
                                            self._stream()))
 
+    def step_begin(self, real, z=None, masks=None, z_g=None, label_smoothing=0.9):
+        """d_compute_grads + the following G step's training forward on its own lane (pipelined
+        step); follow with d_apply, then g_compute_grads(batch) WITHOUT z, then g_apply."""
+        real = _f32(real, self.device, "real_images")
+        b = real.shape[0]
+        self._check_batch(b)
+        z, z_g = _f32(z, self.device, "noise"), _f32(z_g, self.device, "noise")
+        masks = self._masks(masks, b, 2)
+        hp = self._hyper(0.0, 0.5, 0.999, label_smoothing=label_smoothing)
+        _lib.check(self.lib.siggan_step_begin(self._h, _ptr(real), b, _ptr(z), _ptr(masks), _ptr(z_g), C.byref(hp),
+                                              _ptr(self.metrics), self._stream()))
+
+    def train_step(self, real, z_d=None, masks=None, z_g=None, lr_d=2e-4, lr_g=2e-4, beta1=0.5, beta2=0.999, eps=1e-8,
+                   label_smoothing=0.9, clip=None, sync=True):
+        """One pipelined G+D step (n_critic = 1): same results as d_step followed by g_step."""
+        self.step_begin(real, z_d, masks, z_g, label_smoothing)
+        dm = self.d_apply(lr_d, beta1, beta2, eps, clip, 1.0, sync)
+        self.g_compute_grads(real.shape[0])
+        gm = self.g_apply(lr_g, beta1, beta2, eps, clip, 1.0, sync)
+        if sync:
+            dm.update(gm)
+        return dm
+
     def d_apply(self, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8, clip=None, grad_scale=1.0, sync=True):
         hp = self._hyper(lr, beta1, beta2, eps, clip=clip, grad_scale=grad_scale)
         _lib.check(self.lib.siggan_d_apply(self._h, C.byref(hp), _ptr(self.metrics), None, self._stream()))

@@ -139,3 +139,39 @@ def test_trainer_loop_artifacts(tmp_path):
     (tmp_path / "stop.request").write_text("x")
     tr.start_epoch = 0
     assert tr._stop_requested()
+
+
+def test_generation_cli_and_loaders(tmp_path):
+    """SURVEY 8f-1: checkpoint in -> PNGs out.  All three checkpoint layouts + a bare state_dict load;
+    --seed makes the run reproducible; pixels follow the reference's uint8 truncation rule applied to
+    the oracle's images for the same z."""
+    from PIL import Image
+    from signature_gan_amd import generate_signatures as cli
+    from signature_gan_amd.utils.inference import infer_architecture_from_state_dict, load_generator, tensor_to_uint8
+    size, latent = 64, 100
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in I.gen_state(O.g_state_specs(latent, size), SEED["state_g"]).items()}
+    paths = {"A": tmp_path / "a.pt", "sd": tmp_path / "sd.pt", "bare": tmp_path / "bare.pt"}
+    torch.save({"epoch": 1, "generator_state_dict": sd, "config": {"latent_dim": latent, "image_size": size}}, paths["A"])
+    torch.save({"state_dict": sd}, paths["sd"])
+    torch.save(sd, paths["bare"])
+    assert infer_architecture_from_state_dict(sd) == (latent, size)
+    sd128 = I.gen_state(O.g_state_specs(128, 128), 1)
+    assert infer_architecture_from_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd128.items()}) == (128, 128)
+    dev = torch.device("cuda:0")
+    z = torch.from_numpy(I.gen_z(5, latent, 9))
+    want = O.to_uint8(O.g_forward({k: v.clone() for k, v in sd.items()}, z, False, size))[:, 0].numpy()
+    for name, p in paths.items():
+        g, ld = load_generator(str(p), dev)
+        assert ld == latent and not g.training
+        got = tensor_to_uint8(g(z.cuda()))
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1, name      # truncation boundary only
+        assert (got != want).mean() < 1e-3
+    out1, out2 = tmp_path / "o1", tmp_path / "o2"
+    cli.main(["--checkpoint", str(paths["A"]), "--n_samples", "7", "--batch_size", "4", "--seed", "3", "--output_dir", str(out1)])
+    cli.main(["--checkpoint", str(paths["A"]), "--n_samples", "7", "--batch_size", "4", "--seed", "3", "--output_dir", str(out2)])
+    names = sorted(os.listdir(out1))
+    assert names == [f"signature_{i:06d}.png" for i in range(1, 8)]
+    for n in names:
+        a, b = np.asarray(Image.open(out1 / n)), np.asarray(Image.open(out2 / n))
+        assert a.shape == (size, size) and a.dtype == np.uint8 and np.array_equal(a, b)
+    cli.main(["--checkpoint", str(paths["A"]), "--info"])

@@ -222,15 +222,21 @@ def test_execution_modes_are_bitwise_identical():
     real = cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"])))
     masks = [torch.from_numpy(m) for m in I.gen_masks(batch, d_chans(size) * 2, 3)]
     ref = None
-    for graph, overlap in ((False, False), (True, True), (True, False), (False, True)):
+    for graph, overlap, pipelined in ((False, False, False), (True, True, False), (True, False, False), (False, True, False),
+                                      (False, True, True), (False, False, True)):
         eng = make_engine(size, latent, batch, warm=True)
         eng.set_mode(graph=graph, overlap=overlap)
         mets = []
         for s in range(3):
             z1 = cuda(torch.from_numpy(I.gen_z(batch, latent, 50 + s)))
             z2 = cuda(torch.from_numpy(I.gen_z(batch, latent, 60 + s)))
-            mets.append(eng.d_step(real, z1, masks, clip=0.5))
-            mets.append(eng.g_step(batch, z2, clip=0.5))
+            if pipelined:        # siggan_step_begin: the G step's forward runs beside the D step's backward
+                m = eng.train_step(real, z1, masks, z2, clip=0.5)
+                mets.append({k: v for k, v in m.items() if k.startswith("d_")})
+                mets.append({k: v for k, v in m.items() if k.startswith("g_")})
+            else:
+                mets.append(eng.d_step(real, z1, masks, clip=0.5))
+                mets.append(eng.g_step(batch, z2, clip=0.5))
         state = [t.clone() for t in (eng.g_params, eng.d_params, eng.g_exp_avg_sq, eng.d_exp_avg, eng.g_bn_mean, eng.g_bn_var,
                                      eng.g_adam_steps, eng.g_bn_batches)]
         eng.close()
@@ -238,5 +244,5 @@ def test_execution_modes_are_bitwise_identical():
             ref = (state, mets)
         else:
             for a, b in zip(ref[0], state):
-                assert torch.equal(a, b), f"mode graph={graph} overlap={overlap} changed the result"
+                assert torch.equal(a, b), f"mode graph={graph} overlap={overlap} pipelined={pipelined} changed the result"
             assert mets == ref[1]
