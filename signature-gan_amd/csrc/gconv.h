@@ -62,7 +62,6 @@ struct Prof {
     void clear();
 };
 extern Prof* g_prof;
-extern int g_gconv_dma;
 
 void launch_gconv(const GConvArgs& a, hipStream_t st);
 // returns the number of K splits it used (slab must hold max_splits*Cs*16*Cl floats)

@@ -217,196 +217,6 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     }
 }
 
-// ---- LDS-DMA variant: same tiling, the global->LDS staging is done by global_load_lds -------------
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void k_gconv_dma(const GConvArgs a) {
-    static_assert(BM % 32 == 0 && BN % 32 == 0, "tile");
-    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-    constexpr int PA = BM / 32, PB = BN / 32;
-    // LDS tiles are [row][32 floats] = unpadded 128-byte rows filled by LDS-DMA (global_load_lds
-    // dwordx4: each wave instruction deposits 64 lanes x 16 B = 8 whole rows, no VGPRs, no ds_write).
-    // The DMA destination is lane-linear, so the bank swizzle lives on the SOURCE side: lane L of
-    // an instruction (row r = 8j + L/8, slot p = L%8) fetches chunk p ^ (r & 7) of its row, and a
-    // fragment read of chunk q of row r looks at slot q ^ (r & 7) (2-way conflicts on ds_read_b128,
-    // irrelevant at the fp32 MFMA's pace).  K is consumed in the permuted pairing
-    // k = 8c + 4*(lane>>5) + t, identical for A and B, so only the fp32 summation order changes.
-    constexpr int LD = BK;
-    __shared__ __attribute__((aligned(16))) float smem[2 * LD * (BM + BN)];
-    float* const sA = smem;
-    float* const sB = smem + 2 * LD * BM;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-
-    const int tiles_n = a.Co / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
-    const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
-    const int Hr = 1 << a.lgHr, Wr = 1 << a.lgWr;
-    const int ntaps = a.form == 0 ? 16 : 4;
-    const int Ktot = ntaps * a.Ci;
-    const int lgcpt = 31 - __builtin_clz(a.Ci / BK);      // K-tiles per tap = Ci / 32, a power of two
-    const int nk_all = ntaps << lgcpt;
-    // split-K: this block owns K-tiles [k_lo, k_hi)
-    const int kper = (nk_all + gridDim.y - 1) / gridDim.y;
-    const int k_lo = blockIdx.y * kper;
-    const int k_hi = min(nk_all, k_lo + kper);
-    const int nk = k_hi - k_lo;
-
-    // ---- per-lane DMA coordinates: wave w issues instructions j = w + 4p; instruction j fills rows
-    // 8j .. 8j+7 of the tile, lane L -> row 8j + (L >> 3), LDS slot L & 7, source chunk (L & 7) ^ (row & 7)
-    const int slot = lane & 7;
-    const float* a_base[PA];     // &in[n, 0, 0, chunk*4] of the row's image
-    int a_ih0[PA], a_iw0[PA];
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-        const int row = 8 * (wave + 4 * p) + (lane >> 3);
-        const int kc = slot ^ (row & 7);
-        const int m = m0 + row;
-        if (m < a.M) {
-            const int n = m >> (a.lgHr + a.lgWr);
-            const int rh = (m >> a.lgWr) & (Hr - 1), rw = m & (Wr - 1);
-            a_base[p] = a.in + (size_t)n * a.Hi * a.Wi * a.Ci + kc * 4;
-            if (a.form == 0) { a_ih0[p] = 2 * rh - 1; a_iw0[p] = 2 * rw - 1; }
-            else             { a_ih0[p] = rh + ph;    a_iw0[p] = rw + pw; }
-        } else {
-            a_base[p] = a.in; a_ih0[p] = -(1 << 20); a_iw0[p] = -(1 << 20);
-        }
-    }
-    const float* w_cur[PB];
-#pragma unroll
-    for (int p = 0; p < PB; ++p) {
-        const int row = 8 * (wave + 4 * p) + (lane >> 3);
-        w_cur[p] = a.wp + ((size_t)cls * a.Co + n0 + row) * Ktot + (slot ^ (row & 7)) * 4 + (size_t)k_lo * BK;
-    }
-
-    // load cursor: walks (tap, channel chunk) in K order; per-row source pointers are rebuilt only
-    // when the tap changes, otherwise they advance by 32 floats (0 for out-of-image taps, which
-    // read a 16-byte page of zeros so that the DMA stays unconditional)
-    const float* a_cur[PA];
-    int a_step[PA];
-    int l_tap = k_lo >> lgcpt, l_cc = k_lo & ((1 << lgcpt) - 1);
-    auto set_tap = [&]() __attribute__((always_inline)) {
-        int dh, dw;
-        if (a.form == 0) { dh = l_tap >> 2; dw = l_tap & 3; } else { dh = -(l_tap >> 1); dw = -(l_tap & 1); }
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const int ih = a_ih0[p] + dh, iw = a_iw0[p] + dw;
-            const bool ok = (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
-            a_cur[p] = ok ? a_base[p] + ((size_t)(ih * a.Wi + iw) * a.Ci + l_cc * BK) : a.zeros;
-            a_step[p] = ok ? BK : 0;
-        }
-    };
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* glb_ptr;
-    auto dma_tile = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            __builtin_amdgcn_global_load_lds((glb_ptr)a_cur[p], (lds_ptr)(sA + buf * LD * BM + 8 * (wave + 4 * p) * LD), 16, 0, 0);
-            a_cur[p] += a_step[p];
-        }
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            __builtin_amdgcn_global_load_lds((glb_ptr)w_cur[p], (lds_ptr)(sB + buf * LD * BN + 8 * (wave + 4 * p) * LD), 16, 0, 0);
-            w_cur[p] += BK;
-        }
-        if (++l_cc == (1 << lgcpt)) { l_cc = 0; ++l_tap; set_tap(); }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // Tile kt+1 is DMA'd into the other LDS buffer at the start of tile kt (that buffer was last
-    // read in tile kt-1, behind a barrier) and has the whole tile's MFMA time to land; the barrier at
-    // the end of the tile waits for it (hipcc drains vmcnt before a barrier when a DMA is in flight).
-    if (nk > 0) {
-        set_tap();
-        dma_tile(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) dma_tile(buf ^ 1);
-        const int rA = wm * (32 * TM) + li, rB = wn * (32 * TN) + li;      // row & 7 == li & 7 for every 32-row tile
-        const float* pA = sA + buf * LD * BM + rA * LD;
-        const float* pB = sB + buf * LD * BN + rB * LD;
-        const int sw = li & 7;
-        f32x4 fa[2][TM], fb[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(pA + 32 * i * LD + 4 * ((0 + lh) ^ sw));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(pB + 32 * j * LD + 4 * ((0 + lh) ^ sw));
-#pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
-            const int cur = c & 1, nxt = cur ^ 1;
-            if (c + 1 < BK / 8) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    fa[nxt][i] = *reinterpret_cast<const f32x4*>(pA + 32 * i * LD + 4 * ((2 * (c + 1) + lh) ^ sw));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[nxt][j] = *reinterpret_cast<const f32x4*>(pB + 32 * j * LD + 4 * ((2 * (c + 1) + lh) ^ sw));
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep the next chunk's reads ahead of these MFMAs
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed ...
-        __syncthreads();                                    // ... and so have every other wave's
-    }
-
-    // ---- epilogue ----------------------------------------------------------------------
-    float* const outp = gridDim.y > 1 ? a.slab + (size_t)blockIdx.y * a.slab_stride : a.out;
-    const int epi = gridDim.y > 1 ? (int)EPI_RAW : a.epi;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m >= a.M) continue;
-            const int n = m >> (a.lgHr + a.lgWr);
-            size_t opix;
-            if (a.form == 0) {
-                opix = (size_t)m;
-            } else {
-                const int rh = (m >> a.lgWr) & (Hr - 1), rw = m & (Wr - 1);
-                opix = ((size_t)n * a.Ho + 2 * rh + ph) * a.Wo + 2 * rw + pw;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int co = n0 + wn * (32 * TN) + 32 * j + li;
-                float v = acc[i][j][r];
-                const size_t o = opix * a.Co + co;
-                if (epi == EPI_BIAS_LRELU_DROP) {
-                    v += a.bias[co];
-                    v = v > 0.f ? v : v * a.slope;
-                    if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
-                } else if (epi == EPI_AFFINE_RELU) {
-                    v = fmaxf(fmaf(v, a.scale[co], a.shift[co]), 0.f);
-                } else if (epi == EPI_LRELU_BWD) {
-                    const float ar = a.aref[o];
-                    v *= ar > 0.f ? 1.f : a.slope;
-                    if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
-                }
-                outp[o] = v;
-            }
-        }
-    }
-}
-
 // split-K tail: out = epilogue(sum_z slab[z]) over the NHWC output (4 channels per thread)
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int nsplit, int64_t total4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -447,7 +257,6 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int 
 }
 
 Prof* g_prof = nullptr;
-int g_gconv_dma = 0;   // 1: stage conv tiles with LDS-DMA (global_load_lds) instead of registers
 const char* Prof::name(int id) {
     static const char* n[NID] = {"k_gconv<128,128>", "k_gconv<128,64>", "k_gconv<64,64>", "k_gconv<128,32>",
                                  "k_wgrad<64,64>", "k_wgrad<64,128>", "k_wgrad<32,128>", "?"};
@@ -472,8 +281,7 @@ static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     dim3 grid(tiles, nsplit, ncls);
     // algorithmic FLOPs = 2 * M * Co * (taps * Ci) per class (== 2 * conv MACs, padding taps included)
     if (g_prof) g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, st);
-    if (g_gconv_dma) hipLaunchKernelGGL((k_gconv_dma<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
     if (g_prof) g_prof->end(st);
     if (nsplit > 1) {
         const int64_t total4 = (int64_t)a.B * a.Ho * a.Wo * a.Co / 4;

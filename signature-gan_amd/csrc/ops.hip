@@ -860,6 +860,7 @@ __global__ void k_adam_prepare(DevState* st, float* __restrict__ steps, int nten
     __syncthreads();
     for (int i = threadIdx.x; i < ntensors; i += blockDim.x) steps[i] = t;
     if (threadIdx.x != 0) return;
+    st->rng_ctr += 1;                       // every optimiser update starts a new RNG epoch (z, dropout tables)
     const double bc1 = 1.0 - pow(beta1, (double)t);
     const double bc2 = 1.0 - pow(beta2, (double)t);
     st->step_size = (float)(lr / bc1);

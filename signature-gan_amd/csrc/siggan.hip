@@ -44,11 +44,12 @@ static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 struct PhaseKey {
     int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg;
+    float* mt;   // where the phase writes its metrics (caller's buffer, or the workspace one)
     double lr, beta1, beta2, eps;
     float ls, clip, gs;
     bool operator==(const PhaseKey& o) const {
         return phase == o.phase && B == o.B && has_z == o.has_z && has_masks == o.has_masks && g_dirty == o.g_dirty &&
-               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
+               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
                clip == o.clip && gs == o.gs;
     }
 };
@@ -78,6 +79,7 @@ struct siggan_ctx {
     DevState* dev;
     // last *_grads call (for *_apply)
     int pending;   // 0 none, 1 D, 2 G
+    float* metrics_last;   // metrics target of the last *_grads call
     // lanes / graphs
     static constexpr int NEV = 96;
     int mode;
@@ -158,7 +160,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     siggan_ctx* c = new (std::nothrow) siggan_ctx();
     if (!c) return fail(SIGGAN_E_NOMEM, "out of host memory");
     c->cfg = *cfg; c->S = cfg->image_size; c->latent = cfg->latent_dim; c->Bm = cfg->max_batch;
-    c->bound = false; c->g_dirty = c->d_dirty = true; c->pending = 0;
+    c->bound = false; c->g_dirty = c->d_dirty = true; c->pending = 0; c->metrics_last = nullptr;
     build_layout(c);
 
     // ---- workspace carve (two passes: size, then assign) ----------------------------------
@@ -230,7 +232,6 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     DevState h; memset(&h, 0, sizeof h);
     h.seed = cfg->seed; h.rng_ctr = 0; h.grad_mul = 1.f;
     HIPCHK(hipMemcpy(c->dev, &h, sizeof h, hipMemcpyHostToDevice));
-    if (const char* e = getenv("SIGGAN_GCONV_DMA")) g_gconv_dma = atoi(e);   // A/B switch of the conv staging path
     c->mode = SIGGAN_MODE_OVERLAP;   // hipGraph replay measured slower than eager launches on ROCm 7
     c->evi = 0;
     HIPCHK(hipStreamCreateWithFlags(&c->s_m, hipStreamNonBlocking));
@@ -552,7 +553,6 @@ static int check_hyper(const siggan_hyper* hp) {
 static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const int B = k.B;
     const bool drop = c->cfg.dropout > 0.f;
-    launch_tick(c->dev, L.m);
     L.fork(L.a);                                                     // lane a: D's packs, dropout tables, D(real)
     repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
     if (drop) make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, 2, L.a);
@@ -570,7 +570,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         (void)hipEventRecord(c->ev_gfwd, c->s_c);
     }
     d_forward_rows(c, c->img, B, B, drop, L.m, c->slab_k);           // D(fake) into rows [B, 2B)
-    launch_bce(c->logits, 2 * B, B, k.ls, 0.f, c->probs, c->dlogit, c->metrics, 0, L.m);
+    launch_bce(c->logits, 2 * B, B, k.ls, 0.f, c->probs, c->dlogit, k.mt, 0, L.m);
     d_backward_pass(c, L, c->real_stage, B, c->img, 2 * B, drop, true, false);
 }
 
@@ -582,7 +582,6 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         (void)hipStreamWaitEvent(L.m, c->ev_gfwd, 0);
         zg = c->z_g; img = c->img_g;
     } else {
-        launch_tick(c->dev, L.m);
         L.fork(L.a);
         repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
         if (!k.has_z) launch_randn(c->z, (int64_t)B * c->latent, c->dev, 2, L.m);
@@ -591,7 +590,7 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         zg = c->z; img = c->img;
     }
     d_forward_rows(c, img, 0, B, false, L.m, c->slab_k);             // D.eval(): dropout off (train...py:350)
-    launch_bce(c->logits, B, B, 1.0f, 1.0f, c->probs, c->dlogit, c->metrics, 1, L.m);
+    launch_bce(c->logits, B, B, 1.0f, 1.0f, c->probs, c->dlogit, k.mt, 1, L.m);
     d_backward_pass(c, L, img, B, img, B, false, false, true);       // through D into the image; no D weight grads
     g_backward_pass(c, L, zg, B);
 }
@@ -608,7 +607,7 @@ static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const bool clip = k.clip > 0.f;
     if (clip) launch_grad_sumsq(g, n, c->dev, c->partial, L.m);
     launch_adam_prepare(c->dev, steps, nt, k.lr, k.beta1, k.beta2, k.gs, k.clip,
-                        c->metrics + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), L.m);
+                        k.mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), L.m);
     launch_adam(p, g, m, v, n, c->dev, k.beta1, k.beta2, k.eps, (clip || k.gs != 1.0f) ? 1 : 0, L.m);
 }
 
@@ -655,9 +654,11 @@ static int run_phase(siggan_ctx* c, const PhaseKey& k, hipStream_t u) {
     return SIGGAN_OK;
 }
 
-static PhaseKey make_key(siggan_ctx* c, int phase, int B, bool has_z, bool has_masks, const siggan_hyper* hp) {
+static PhaseKey make_key(siggan_ctx* c, int phase, int B, bool has_z, bool has_masks, const siggan_hyper* hp,
+                         float* metrics_dev) {
     PhaseKey k; memset(&k, 0, sizeof k);
     k.phase = phase; k.B = B; k.has_z = has_z; k.has_masks = has_masks;
+    k.mt = metrics_dev ? metrics_dev : c->metrics;
     if (phase <= 1) { k.g_dirty = c->g_dirty; k.d_dirty = c->d_dirty; k.ls = hp->label_smoothing; }
     else {
         k.lr = hp->lr; k.beta1 = hp->beta1; k.beta2 = hp->beta2; k.eps = hp->eps;
@@ -668,9 +669,9 @@ static PhaseKey make_key(siggan_ctx* c, int phase, int B, bool has_z, bool has_m
 }
 
 static int finish_metrics(siggan_ctx* c, float* metrics_dev, float* metrics_host, hipStream_t s) {
-    if (metrics_dev) HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (metrics_host) {
-        HIPCHK(hipMemcpyAsync(metrics_host, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(metrics_host, metrics_dev ? metrics_dev : c->metrics, SIGGAN_M_COUNT * sizeof(float),
+                              hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
     return SIGGAN_OK;
@@ -737,13 +738,13 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     if (masks_dev) HIPCHK(hipMemcpyAsync(c->mask_stage, masks_dev, (size_t)2 * B * sumC * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (zg_dev) HIPCHK(hipMemcpyAsync(c->z_g, zg_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     c->zg_stash = (!spec_g && zg_dev) ? B : 0;
-    PhaseKey k = make_key(c, 0, B, z_dev != nullptr, masks_dev != nullptr, hp);
+    PhaseKey k = make_key(c, 0, B, z_dev != nullptr, masks_dev != nullptr, hp, metrics_dev);
+    c->metrics_last = k.mt;
     k.spec_g = spec_g; k.has_zg = spec_g && zg_dev != nullptr;
     if ((rc = run_phase(c, k, s))) return rc;
     c->g_dirty = c->d_dirty = false;
     if (spec_g) { c->g_fwd_pending = B; c->g_dirty = true; }   // running statistics moved
     c->pending = 1;
-    if (metrics_dev) HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, s));
     return SIGGAN_OK;
 }
 
@@ -768,7 +769,11 @@ static int apply_common(siggan_ctx* c, int which, const siggan_hyper* hp, float*
     for (const float* p : need)
         if (!p) return fail(SIGGAN_E_STATE, "gradient / Adam arenas were not bound");
     hipStream_t s = (hipStream_t)stream;
-    const PhaseKey k = make_key(c, which == 1 ? 2 : 3, 0, false, false, hp);
+    // metrics of a step live in ONE buffer: the one the *_grads call named (its losses are already there)
+    if (!metrics_dev) metrics_dev = c->metrics_last != c->metrics ? c->metrics_last : nullptr;
+    else if (c->metrics_last && metrics_dev != c->metrics_last)
+        HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics_last, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    const PhaseKey k = make_key(c, which == 1 ? 2 : 3, 0, false, false, hp, metrics_dev);
     if ((rc = run_phase(c, k, s))) return rc;
     if (which == 0) c->g_dirty = true; else c->d_dirty = true;
     c->pending = 0;
@@ -781,7 +786,7 @@ extern "C" int siggan_d_apply(siggan_ctx* c, const siggan_hyper* hp, float* metr
 
 extern "C" int siggan_d_step(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
                              const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
-    int rc = siggan_d_grads(c, real_dev, batch, z_dev, masks_dev, hp, nullptr, stream);
+    int rc = siggan_d_grads(c, real_dev, batch, z_dev, masks_dev, hp, metrics_dev, stream);
     if (rc) return rc;
     return siggan_d_apply(c, hp, metrics_dev, metrics_host, stream);
 }
@@ -800,14 +805,14 @@ extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, 
     if (!spec && !z_dev && c->zg_stash == B) z_dev = c->z_g;          // z given to a step_begin that could not pipeline
     c->zg_stash = 0;
     if (!spec && z_dev && z_dev != c->z) HIPCHK(hipMemcpyAsync(c->z, z_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
-    PhaseKey k = make_key(c, 1, B, z_dev != nullptr, false, hp);
+    PhaseKey k = make_key(c, 1, B, z_dev != nullptr, false, hp, metrics_dev);
+    c->metrics_last = k.mt;
     k.spec_g = spec;
     if ((rc = run_phase(c, k, s))) return rc;
     c->g_fwd_pending = 0;
     c->d_dirty = false;
     c->g_dirty = true;                 // the training forward moved the BatchNorm running statistics
     c->pending = 2;
-    if (metrics_dev) HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, s));
     return SIGGAN_OK;
 }
 
@@ -817,7 +822,7 @@ extern "C" int siggan_g_apply(siggan_ctx* c, const siggan_hyper* hp, float* metr
 
 extern "C" int siggan_g_step(siggan_ctx* c, int32_t batch, const float* z_dev, const siggan_hyper* hp, float* metrics_dev,
                              float* metrics_host, void* stream) {
-    int rc = siggan_g_grads(c, batch, z_dev, hp, nullptr, stream);
+    int rc = siggan_g_grads(c, batch, z_dev, hp, metrics_dev, stream);
     if (rc) return rc;
     return siggan_g_apply(c, hp, metrics_dev, metrics_host, stream);
 }
