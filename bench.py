@@ -133,10 +133,16 @@ def main():
         eng.set_mode(graph=False, overlap=not args.serialize)
         top = max(recs, key=lambda r: r["ms"])
         ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+        traffic = None                  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["per_launch_bytes"][top["name"]]["total"]
+        except (OSError, KeyError, ValueError):
+            pass
         fam_ms, fam_fl = sum(r["ms"] for r in recs), sum(r["flops"] for r in recs)
         roofline = {
             "bound": "mfma", "kernel": top["name"], "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
             "launches_per_step": top["launches"] / args.steps,
             "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
             "gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 4),

@@ -16,6 +16,7 @@
 // Global->LDS staging is register-staged and software-pipelined one K-tile ahead (loads for tile
 // t+1 are issued before the MFMAs of tile t, written to the other LDS buffer after them).
 #include "gconv.h"
+#include <hip/hip_ext.h>
 
 namespace siggan {
 
@@ -262,13 +263,16 @@ const char* Prof::name(int id) {
                                  "k_wgrad<64,64>", "k_wgrad<64,128>", "k_wgrad<32,128>", "?"};
     return n[id < 0 || id >= NID ? NID - 1 : id];
 }
-void Prof::begin(int id, double flops, hipStream_t st) {
+// The two events of a record are handed to hipExtLaunchKernelGGL, which stamps them with the
+// kernel's own begin / end (the dispatch's completion-signal timestamps), so a record's elapsed time
+// is the kernel duration rocprofv3 reports -- not the launch-to-launch gap a plain
+// hipEventRecord pair would include.
+void Prof::begin(int id, double flops, hipStream_t) {
     Rec r; r.id = id; r.flops = flops;
     (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
-    (void)hipEventRecord(r.e0, st);
     recs.push_back(r);
 }
-void Prof::end(hipStream_t st) { (void)hipEventRecord(recs.back().e1, st); }
+void Prof::end(hipStream_t) {}
 void Prof::clear() {
     for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     recs.clear();
@@ -280,9 +284,12 @@ static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     const int ncls = a.form == 0 ? 1 : 4;
     dim3 grid(tiles, nsplit, ncls);
     // algorithmic FLOPs = 2 * M * Co * (taps * Ci) per class (== 2 * conv MACs, padding taps included)
-    if (g_prof) g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, st);
-    hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
-    if (g_prof) g_prof->end(st);
+    if (g_prof) {
+        g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, st);
+        hipExtLaunchKernelGGL((k_gconv<BM, BN, WM, WN>), grid, dim3(256), 0, st, g_prof->recs.back().e0, g_prof->recs.back().e1, 0, a);
+    } else {
+        hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+    }
     if (nsplit > 1) {
         const int64_t total4 = (int64_t)a.B * a.Ho * a.Wo * a.Co / 4;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a, nsplit, total4);
@@ -450,10 +457,16 @@ int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
     a.kchunk = per * BK;
     nsplit = (ktiles + per - 1) / per;
     dim3 grid(tiles, 1, nsplit);
-    if (g_prof) g_prof->begin(small ? 6 : 4, 2.0 * a.Cs * (double)N * a.K, st);
-    if (small) hipLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad<64, 64, 2, 2>), grid, dim3(256), 0, st, a);
-    if (g_prof) g_prof->end(st);
+    if (g_prof) {
+        g_prof->begin(small ? 6 : 4, 2.0 * a.Cs * (double)N * a.K, st);
+        hipEvent_t e0 = g_prof->recs.back().e0, e1 = g_prof->recs.back().e1;
+        if (small) hipExtLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL((k_wgrad<64, 64, 2, 2>), grid, dim3(256), 0, st, e0, e1, 0, a);
+    } else if (small) {
+        hipLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((k_wgrad<64, 64, 2, 2>), grid, dim3(256), 0, st, a);
+    }
     return nsplit;
 }
 
