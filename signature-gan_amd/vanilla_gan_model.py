@@ -86,13 +86,33 @@ class VanillaGAN(nn.Module):
         return m
 
     def train_step(self, real_images: torch.Tensor, n_critic: int = 1) -> Dict[str, float]:
-        metrics: Dict[str, float] = {}
-        for i in range(n_critic):
-            d = self.train_discriminator_step(real_images)
-            if i == n_critic - 1:
-                metrics.update(d)
-        metrics.update(self.train_generator_step(real_images.size(0)))
-        return metrics
+        """vanilla_gan_model.py:308-336.  With n_critic == 1 the two steps run as ONE pipelined engine
+        step (the G step's forward beside the D step's backward; bit-identical results)."""
+        if n_critic != 1:
+            metrics: Dict[str, float] = {}
+            for i in range(n_critic):
+                d = self.train_discriminator_step(real_images)
+                if i == n_critic - 1:
+                    metrics.update(d)
+            metrics.update(self.train_generator_step(real_images.size(0)))
+            return metrics
+        self.discriminator.train()
+        self.generator.train()          # the mode the reference leaves G in after train_generator_step
+        hd, hg = self.d_optimizer.hyper(), self.g_optimizer.hyper()
+        self.d_optimizer._sync_views(); self.g_optimizer._sync_views()
+        real = real_images.to(self._device, torch.float32)
+        e = self.engine
+        e.step_begin(real, None, None, None, self.label_smoothing)
+        m = e.d_apply(hd["lr"], hd["beta1"], hd["beta2"], hd["eps"], None, 1.0, sync=False) or {}
+        e.g_compute_grads(real.shape[0])
+        m = e.g_apply(hg["lr"], hg["beta1"], hg["beta2"], hg["eps"], None, 1.0, sync=True)
+        host = e.metrics.cpu()
+        from ._lib import METRIC_INDEX
+        out = {k: float(host[METRIC_INDEX[k]]) for k in e.D_KEYS + e.G_KEYS}
+        self.d_losses.append(out["d_loss"]); self.g_losses.append(out["g_loss"])
+        self.global_step += 1
+        self.discriminator.eval()       # reference: train_generator_step ends with D in eval mode
+        return out
 
     # ---- generation (vanilla_gan_model.py:338-407) ---------------------------------------------------
     @torch.no_grad()

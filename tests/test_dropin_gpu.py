@@ -62,6 +62,9 @@ def test_vanilla_gan_steps_match_oracle_and_checkpoint_roundtrip(tmp_path):
     assert all(np.isfinite(v) for v in dm.values() if v is not None) and m.global_step == 1
     step = m.train_step(x, n_critic=2)
     assert "g_loss" in step and "d_loss" in step and m.global_step == 3
+    step = m.train_step(x)                        # n_critic == 1: the pipelined engine step
+    assert set(step) >= {"d_loss", "d_real_acc", "d_fake_mean", "g_loss", "g_fake_mean"} and m.global_step == 4
+    assert all(np.isfinite(v) for v in step.values()) and not m.discriminator.training and m.generator.training
 
     # ---- layout B checkpoint: structure equals the reference's, safe loader accepts it ----------
     man = json.load(open(os.path.join(GOLDEN, "checkpoint_manifest.json")))["s64"]
@@ -80,7 +83,7 @@ def test_vanilla_gan_steps_match_oracle_and_checkpoint_roundtrip(tmp_path):
     params = [torch.nn.Parameter(torch.zeros_like(p)) for p in m.generator.parameters()]
     stock = torch.optim.Adam(params, lr=2e-4, betas=(0.5, 0.999))
     stock.load_state_dict(ck["g_optimizer_state_dict"])
-    assert float(stock.state[params[0]]["step"]) == 2.0   # two G updates so far
+    assert float(stock.state[params[0]]["step"]) == 3.0   # three G updates so far
 
     # round trip into a fresh model: identical weights, moments, next step identical
     m2 = VanillaGAN.from_checkpoint(tmp_path / "ck", device="cuda:0")
