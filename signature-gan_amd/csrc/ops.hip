@@ -412,128 +412,173 @@ void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int 
 }
 
 // =========================================================================================
-// Generator final 3x3 conv (C -> 1) + tanh
+// Generator final 3x3 conv (32 -> 1) + tanh, and its backward
 // =========================================================================================
-// 8 lanes per pixel (4 channels each, weights in registers), 8 pixels per lane group: every tap is
-// one coalesced 128-byte read per pixel; the 8 partial dot products are combined with shuffles.
+// All three kernels: 8 lanes per pixel (4 channels each, weights in registers) x 32 pixels along a
+// row; a block owns an RY-row strip of one image and reads the (RY+2) x 3 neighbourhood it needs
+// with unconditional loads (clamped address, value selected to 0 outside the image), so every load
+// of the strip is in flight at once.
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v ldg4(const float* p) { return *reinterpret_cast<const f4v*>(p); }
+__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+struct StripId { int n, y0, x; };
+template <int RY>
+__device__ __forceinline__ StripId strip_of(int sid, int S, int xi) {
+    const int nbx = S >> 5, nby = S / RY;
+    StripId r;
+    r.x = (sid % nbx) * 32 + xi; sid /= nbx;
+    r.y0 = (sid % nby) * RY; r.n = sid / nby;
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ act, const float* __restrict__ W,
-                                                   const float* __restrict__ b, float* __restrict__ img, int B, int S,
-                                                   int C) {
-    const int G = C / 4;                               // lanes per pixel (8 for C = 32)
-    const int c4 = threadIdx.x % G, grp = threadIdx.x / G, ngrp = 256 / G;
-    float4 w[9];
+                                                   const float* __restrict__ b, float* __restrict__ img, int S) {
+    constexpr int RY = 4, C = 32;
+    const int c4 = threadIdx.x & 7;
+    const StripId t = strip_of<RY>(blockIdx.x, S, threadIdx.x >> 3);
+    f4v w[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-        w[t] = make_float4(W[(c4 * 4 + 0) * 9 + t], W[(c4 * 4 + 1) * 9 + t], W[(c4 * 4 + 2) * 9 + t], W[(c4 * 4 + 3) * 9 + t]);
+    for (int k = 0; k < 9; ++k)
+        w[k] = f4v{W[(c4 * 4 + 0) * 9 + k], W[(c4 * 4 + 1) * 9 + k], W[(c4 * 4 + 2) * 9 + k], W[(c4 * 4 + 3) * 9 + k]};
     const float bias = b[0];
-    const int64_t total = (int64_t)B * S * S;
-    const int64_t base = (int64_t)blockIdx.x * ngrp * 8;
-#pragma unroll 2
-    for (int it = 0; it < 8; ++it) {
-        const int64_t pix = base + it * ngrp + grp;
-        float acc = 0.f;
-        if (pix < total) {
-            const int x = (int)(pix % S), y = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
+    const float* base = act + (size_t)t.n * S * S * C + c4 * 4;
+    f4v v[RY + 2][3];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int yy = y + kh - 1;
+    for (int r = 0; r < RY + 2; ++r) {
+        const int yy = t.y0 + r - 1, yc = clampi(yy, S - 1);
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int xx = x + kw - 1;
-                    if ((unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S) {
-                        const float4 v = *(const float4*)(act + (((size_t)n * S + yy) * S + xx) * C + c4 * 4);
-                        const float4 ww = w[kh * 3 + kw];
-                        acc = fmaf(v.x, ww.x, acc); acc = fmaf(v.y, ww.y, acc); acc = fmaf(v.z, ww.z, acc); acc = fmaf(v.w, ww.w, acc);
-                    }
-                }
-            }
+        for (int d = 0; d < 3; ++d) {
+            const int xx = t.x + d - 1, xc = clampi(xx, S - 1);
+            const f4v q = ldg4(base + ((size_t)yc * S + xc) * C);
+            v[r][d] = (yy == yc && xx == xc) ? q : f4v{0.f, 0.f, 0.f, 0.f};
         }
-        for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
-        if (pix < total && c4 == 0) img[pix] = tanhf(acc + bias);
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const f4v a = v[r + kh][kw], ww = w[kh * 3 + kw];
+                acc = fmaf(a.x, ww.x, acc); acc = fmaf(a.y, ww.y, acc); acc = fmaf(a.z, ww.z, acc); acc = fmaf(a.w, ww.w, acc);
+            }
+        acc += __shfl_xor(acc, 4, 8); acc += __shfl_xor(acc, 2, 8); acc += __shfl_xor(acc, 1, 8);
+        if (c4 == 0) img[((size_t)t.n * S + t.y0 + r) * S + t.x] = tanhf(acc + bias);
     }
 }
 void launch_final_fwd(const float* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s) {
-    const int ppb = (256 / (C / 4)) * 8;
-    hipLaunchKernelGGL(k_final_fwd, dim3(cdiv((int64_t)B * S * S, ppb)), dim3(256), 0, s, act, W, b, img, B, S, C);
+    (void)C;                                            // host checks C == 32, S % 32 == 0
+    hipLaunchKernelGGL(k_final_fwd, dim3(B * (S / 4) * (S / 32)), dim3(256), 0, s, act, W, b, img, S);
 }
 
 __global__ __launch_bounds__(256) void k_final_dgrad(const float* __restrict__ dpre, const float* __restrict__ W,
-                                                     float* __restrict__ dact, int B, int S, int C) {
-    const int G = C / 4;
-    const int c4 = threadIdx.x % G, grp = threadIdx.x / G, ngrp = 256 / G;
-    float4 w[9];
+                                                     float* __restrict__ dact, int S) {
+    constexpr int RY = 4, C = 32;
+    const int c4 = threadIdx.x & 7;
+    const StripId t = strip_of<RY>(blockIdx.x, S, threadIdx.x >> 3);
+    f4v w[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-        w[t] = make_float4(W[(c4 * 4 + 0) * 9 + t], W[(c4 * 4 + 1) * 9 + t], W[(c4 * 4 + 2) * 9 + t], W[(c4 * 4 + 3) * 9 + t]);
-    const int64_t total = (int64_t)B * S * S;
-    const int64_t base = (int64_t)blockIdx.x * ngrp * 8;
-#pragma unroll 2
-    for (int it = 0; it < 8; ++it) {
-        const int64_t pix = base + it * ngrp + grp;
-        if (pix >= total) break;
-        const int x = (int)(pix % S), y = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 9; ++k)
+        w[k] = f4v{W[(c4 * 4 + 0) * 9 + k], W[(c4 * 4 + 1) * 9 + k], W[(c4 * 4 + 2) * 9 + k], W[(c4 * 4 + 3) * 9 + k]};
+    const float* base = dpre + (size_t)t.n * S * S;
+    float d[RY + 2][3];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int yy = y + 1 - kh;
+    for (int r = 0; r < RY + 2; ++r) {
+        const int yy = t.y0 + r - 1, yc = clampi(yy, S - 1);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int xx = x + 1 - kw;
-                if ((unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S) {
-                    const float d = dpre[((size_t)n * S + yy) * S + xx];
-                    const float4 ww = w[kh * 3 + kw];
-                    acc.x = fmaf(d, ww.x, acc.x); acc.y = fmaf(d, ww.y, acc.y); acc.z = fmaf(d, ww.z, acc.z); acc.w = fmaf(d, ww.w, acc.w);
-                }
-            }
+        for (int k = 0; k < 3; ++k) {
+            const int xx = t.x + k - 1, xc = clampi(xx, S - 1);
+            const float q = base[yc * S + xc];
+            d[r][k] = (yy == yc && xx == xc) ? q : 0.f;
         }
-        *(float4*)(dact + (size_t)pix * C + c4 * 4) = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {                 // dact[y][x] += dpre[y + 1 - kh][x + 1 - kw] * W[kh][kw]
+                const float g = d[r + 2 - kh][2 - kw];
+                const f4v ww = w[kh * 3 + kw];
+                acc.x = fmaf(g, ww.x, acc.x); acc.y = fmaf(g, ww.y, acc.y); acc.z = fmaf(g, ww.z, acc.z); acc.w = fmaf(g, ww.w, acc.w);
+            }
+        *reinterpret_cast<f4v*>(dact + (((size_t)t.n * S + t.y0 + r) * S + t.x) * C + c4 * 4) = acc;
     }
 }
 void launch_final_dgrad(const float* dpre, const float* W, float* dact, int B, int S, int C, hipStream_t s) {
-    const int ppb = (256 / (C / 4)) * 8;
-    hipLaunchKernelGGL(k_final_dgrad, dim3(cdiv((int64_t)B * S * S, ppb)), dim3(256), 0, s, dpre, W, dact, B, S, C);
+    (void)C;
+    hipLaunchKernelGGL(k_final_dgrad, dim3(B * (S / 4) * (S / 32)), dim3(256), 0, s, dpre, W, dact, S);
 }
 
-// block = C channel lanes x (256/C) pixel lanes; partial[chunk][C*9 + 1]
+// dW[c][kh][kw] = sum act[n][y][x][c] * dpre[n][y - kh + 1][x - kw + 1];  db = sum dpre.
+// Each block walks strips (grid-stride), keeps 9 x 4 weight sums + the bias sum per thread, folds the
+// 32 pixel lanes (shuffles inside a wave, LDS across the 4 waves, fixed order) and writes one
+// partial row [C*9 + 1]; k_rows_sum adds the rows.
 __global__ __launch_bounds__(256) void k_final_wgrad(const float* __restrict__ dpre, const float* __restrict__ act,
-                                                     float* __restrict__ partial, int B, int S, int C, int ppb) {
-    __shared__ float sh[256 * 10];
-    const int ci = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
-    const int64_t total = (int64_t)B * S * S;
-    const int64_t p0 = (int64_t)blockIdx.x * ppb;
-    const int64_t p1 = p0 + ppb < total ? p0 + ppb : total;
-    float acc[9], sdb = 0.f;
+                                                     float* __restrict__ partial, int S, int nstrips) {
+    constexpr int RY = 8, C = 32;
+    __shared__ float sh[4][8][37];
+    const int c4 = threadIdx.x & 7, wave = threadIdx.x >> 6;
+    f4v acc[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-    for (int64_t pix = p0 + pl; pix < p1; pix += npl) {
-        const int w = (int)(pix % S), h = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
-        const float av = act[(size_t)pix * C + ci];
-        if (ci == 0) sdb += dpre[pix];
+    for (int k = 0; k < 9; ++k) acc[k] = f4v{0.f, 0.f, 0.f, 0.f};
+    float sdb = 0.f;
+    for (int sid = blockIdx.x; sid < nstrips; sid += gridDim.x) {
+        const StripId t = strip_of<RY>(sid, S, threadIdx.x >> 3);
+        const float* dbase = dpre + (size_t)t.n * S * S;
+        const float* abase = act + (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
+        float d[RY + 2][3];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int hh = h - kh + 1;
+        for (int r = 0; r < RY + 2; ++r) {
+            const int yy = t.y0 + r - 1, yc = clampi(yy, S - 1);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ww = w - kw + 1;
-                if ((unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S)
-                    acc[kh * 3 + kw] = fmaf(av, dpre[((size_t)n * S + hh) * S + ww], acc[kh * 3 + kw]);
+            for (int k = 0; k < 3; ++k) {
+                const int xx = t.x + k - 1, xc = clampi(xx, S - 1);
+                const float q = dbase[yc * S + xc];
+                d[r][k] = (yy == yc && xx == xc) ? q : 0.f;
             }
+        }
+        f4v a[RY];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) a[r] = ldg4(abase + (size_t)r * S * C);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            sdb += d[r + 1][1];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float g = d[r + 2 - kh][2 - kw];
+                    f4v& q = acc[kh * 3 + kw];
+                    q.x = fmaf(a[r].x, g, q.x); q.y = fmaf(a[r].y, g, q.y); q.z = fmaf(a[r].z, g, q.z); q.w = fmaf(a[r].w, g, q.w);
+                }
         }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) sh[threadIdx.x * 10 + t] = acc[t];
-    sh[threadIdx.x * 10 + 9] = sdb;
+    for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            acc[k].x += __shfl_xor(acc[k].x, o); acc[k].y += __shfl_xor(acc[k].y, o);
+            acc[k].z += __shfl_xor(acc[k].z, o); acc[k].w += __shfl_xor(acc[k].w, o);
+        }
+        sdb += __shfl_xor(sdb, o);
+    }
+    if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            sh[wave][c4][0 * 9 + k] = acc[k].x; sh[wave][c4][1 * 9 + k] = acc[k].y;
+            sh[wave][c4][2 * 9 + k] = acc[k].z; sh[wave][c4][3 * 9 + k] = acc[k].w;
+        }
+        sh[wave][c4][36] = sdb;
+    }
     __syncthreads();
     float* out = partial + (size_t)blockIdx.x * (C * 9 + 1);
     for (int o = threadIdx.x; o < C * 9 + 1; o += 256) {
-        float s = 0.f;
-        if (o < C * 9) {
-            const int c = o / 9, t = o % 9;
-            for (int k = 0; k < npl; ++k) s += sh[(k * C + c) * 10 + t];
-        } else {
-            for (int k = 0; k < npl; ++k) s += sh[(k * C) * 10 + 9];
-        }
-        out[o] = s;
+        const int g = o < C * 9 ? o / 36 : 0, j = o < C * 9 ? o % 36 : 36;     // channel c = 4*g + j/9, tap j%9
+        out[o] = ((sh[0][g][j] + sh[1][g][j]) + sh[2][g][j]) + sh[3][g][j];
     }
 }
 __global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ partial, int nch, int width, float* __restrict__ o0, int n0,
@@ -548,165 +593,209 @@ __global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ par
 }
 void launch_final_wgrad(const float* dpre, const float* act, float* dW, float* db, float* partial, int B, int S, int C,
                         hipStream_t s) {
-    const int64_t total = (int64_t)B * S * S;
-    int nch = 1024;
-    int ppb = cdiv(total, nch);
-    ppb = ((ppb + 7) / 8) * 8;
-    nch = cdiv(total, ppb);
-    hipLaunchKernelGGL(k_final_wgrad, dim3(nch), dim3(256), 0, s, dpre, act, partial, B, S, C, ppb);
+    const int nstrips = B * (S / 8) * (S / 32);
+    const int nch = nstrips < 1024 ? nstrips : 1024;
+    hipLaunchKernelGGL(k_final_wgrad, dim3(nch), dim3(256), 0, s, dpre, act, partial, S, nstrips);
     hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 64)), dim3(1024), 0, s, partial, nch, C * 9 + 1, dW, C * 9, db);
 }
 
 // =========================================================================================
-// Discriminator first block (Cin = 1)
+// Discriminator first block (1 -> 64, 4x4 stride 2 pad 1) and its backward
 // =========================================================================================
 __device__ __forceinline__ const float* seg_ptr(const float* x0, int n0, const float* x1, int n, int S) {
     return n < n0 ? x0 + (size_t)n * S * S : x1 + (size_t)(n - n0) * S * S;
 }
+// zero-padded input rows [2*oh0 - 1, 2*oh0 + 2*RY] x cols [-1, S] of one image into LDS
+template <int RY>
+__device__ __forceinline__ void stage_x(float* sx, const float* xp, int oh0, int S) {
+    const int Wp = S + 2;
+    for (int i = threadIdx.x; i < (2 * RY + 2) * Wp; i += 256) {
+        const int r = i / Wp, cc = i - r * Wp, ih = 2 * oh0 - 1 + r, iw = cc - 1;
+        sx[i] = ((unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) ? xp[ih * S + iw] : 0.f;
+    }
+}
 
-// thread = 4 output channels (16 taps x 4 weights in registers) x 8 output pixels; the 16 lanes
-// of a pixel read the same 16 input values (broadcast) and write 256 contiguous bytes.
+// thread = 4 output channels (16 taps x 4 weights in registers); 16 channel lanes x 16 pixel lanes;
+// a block produces RY output rows of one image from an LDS copy of the input rows (broadcast reads)
+// and writes 256 contiguous bytes per pixel.
 __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x0, int n0, const float* __restrict__ x1,
                                                    const float* __restrict__ W, const float* __restrict__ b,
                                                    const float* __restrict__ noise, float slope,
-                                                   float* __restrict__ out, int B, int S, int C) {
-    const int Q = C / 4, ngrp = 256 / Q, Ho = S / 2;
-    const int q = threadIdx.x % Q, grp = threadIdx.x / Q;
-    float4 w[16];
+                                                   float* __restrict__ out, int S) {
+    constexpr int RY = 2, C = 64;
+    __shared__ float sx[(2 * RY + 2) * 130];
+    const int Ho = S >> 1, nby = Ho / RY, Wp = S + 2;
+    const int n = blockIdx.x / nby, oh0 = (blockIdx.x % nby) * RY;
+    const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    stage_x<RY>(sx, seg_ptr(x0, n0, x1, n, S), oh0, S);
+    f4v w[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t)
-        w[t] = make_float4(W[(q * 4 + 0) * 16 + t], W[(q * 4 + 1) * 16 + t], W[(q * 4 + 2) * 16 + t], W[(q * 4 + 3) * 16 + t]);
-    const float4 bias = *(const float4*)(b + q * 4);
-    const int64_t total = (int64_t)B * Ho * Ho;
-    const int64_t base = (int64_t)blockIdx.x * ngrp * 8;
-    for (int it = 0; it < 8; ++it) {
-        const int64_t pix = base + it * ngrp + grp;
-        if (pix >= total) break;
-        const int ow = (int)(pix % Ho), oh = (int)((pix / Ho) % Ho), n = (int)(pix / ((int64_t)Ho * Ho));
-        const float* xp = seg_ptr(x0, n0, x1, n, S);
-        float4 acc = bias;
+        w[t] = f4v{W[(q * 4 + 0) * 16 + t], W[(q * 4 + 1) * 16 + t], W[(q * 4 + 2) * 16 + t], W[(q * 4 + 3) * 16 + t]};
+    const f4v bias = ldg4(b + q * 4);
+    f4v nz = {1.f, 1.f, 1.f, 1.f};
+    if (noise) nz = ldg4(noise + (size_t)n * C + q * 4);
+    __syncthreads();
+    for (int p = pl; p < RY * Ho; p += 16) {
+        const int r = p / Ho, ow = p - r * Ho;
+        const float* xr = sx + (2 * r) * Wp + 2 * ow;
+        f4v acc = bias;
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
-            const int ih = 2 * oh - 1 + kh;
+        for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 4; ++kw) {
-                const int iw = 2 * ow - 1 + kw;
-                const float xv = ((unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) ? xp[ih * S + iw] : 0.f;
-                const float4 wv = w[kh * 4 + kw];
+                const float xv = xr[kh * Wp + kw];
+                const f4v wv = w[kh * 4 + kw];
                 acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);
                 acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
             }
-        }
         acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
         acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
-        if (noise) {
-            const float4 nz = *(const float4*)(noise + (size_t)n * C + q * 4);
-            acc.x *= nz.x; acc.y *= nz.y; acc.z *= nz.z; acc.w *= nz.w;
-        }
-        *(float4*)(out + (size_t)pix * C + q * 4) = acc;
+        if (noise) { acc.x *= nz.x; acc.y *= nz.y; acc.z *= nz.z; acc.w *= nz.w; }
+        *reinterpret_cast<f4v*>(out + (((size_t)n * Ho + oh0 + r) * Ho + ow) * C + q * 4) = acc;
     }
 }
 void launch_conv1_fwd(const float* x0, int n0, const float* x1, const float* W, const float* b, const float* noise,
                       float slope, float* out, int B, int S, int C, hipStream_t s) {
-    const int ppb = (256 / (C / 4)) * 8;
-    hipLaunchKernelGGL(k_conv1_fwd, dim3(cdiv((int64_t)B * (S / 2) * (S / 2), ppb)), dim3(256), 0, s, x0, n0, x1, W, b, noise,
-                       slope, out, B, S, C);
+    (void)C;                                            // host checks C == 64, S in {64, 128}
+    hipLaunchKernelGGL(k_conv1_fwd, dim3(B * (S / 4)), dim3(256), 0, s, x0, n0, x1, W, b, noise, slope, out, S);
 }
 
-// block = C channel lanes x (256/C) pixel lanes; partial[chunk][C*17]  (16 taps + bias)
+// dW[co][kh][kw] = sum dv[n][oh][ow][co] * x[n][2oh-1+kh][2ow-1+kw];  db[co] = sum dv.
+// Same thread map as the forward; 17 x 4 sums per thread, folded over the 16 pixel lanes at the end
+// (shuffles, then LDS across the waves); partial row = [C*16 weights (co*16 + tap)] [C biases].
 __global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ dv, const float* __restrict__ x0, int n0,
-                                                     const float* __restrict__ x1, float* __restrict__ partial, int B,
-                                                     int S, int C, int ppb) {
-    extern __shared__ float sh[];   // [256][17]
-    const int co = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C, Ho = S / 2;
-    const int64_t total = (int64_t)B * Ho * Ho;
-    const int64_t p0 = (int64_t)blockIdx.x * ppb;
-    const int64_t p1 = p0 + ppb < total ? p0 + ppb : total;
-    float acc[17];
+                                                     const float* __restrict__ x1, float* __restrict__ partial, int S,
+                                                     int nstrips) {
+    constexpr int RY = 4, C = 64;
+    __shared__ float sx[(2 * RY + 2) * 130];
+    __shared__ float sh[4][16][69];
+    const int Ho = S >> 1, nby = Ho / RY, Wp = S + 2;
+    const int q = threadIdx.x & 15, pl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    f4v acc[17];
 #pragma unroll
-    for (int t = 0; t < 17; ++t) acc[t] = 0.f;
-    for (int64_t pix = p0 + pl; pix < p1; pix += npl) {
-        const int ow = (int)(pix % Ho), oh = (int)((pix / Ho) % Ho), n = (int)(pix / ((int64_t)Ho * Ho));
-        const float* xp = seg_ptr(x0, n0, x1, n, S);
-        const float g = dv[(size_t)pix * C + co];
-        acc[16] += g;
+    for (int t = 0; t < 17; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int sid = blockIdx.x; sid < nstrips; sid += gridDim.x) {
+        const int n = sid / nby, oh0 = (sid % nby) * RY;
+        __syncthreads();
+        stage_x<RY>(sx, seg_ptr(x0, n0, x1, n, S), oh0, S);
+        __syncthreads();
+        const float* gbase = dv + ((size_t)n * Ho + oh0) * Ho * C + q * 4;
+        for (int p0 = pl; p0 < RY * Ho; p0 += 64) {
+            f4v g[4];
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
-            const int ih = 2 * oh - 1 + kh;
+            for (int u = 0; u < 4; ++u) g[u] = ldg4(gbase + (size_t)(p0 + 16 * u) * C);
 #pragma unroll
-            for (int kw = 0; kw < 4; ++kw) {
-                const int iw = 2 * ow - 1 + kw;
-                const float xv = ((unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) ? xp[ih * S + iw] : 0.f;
-                acc[kh * 4 + kw] = fmaf(g, xv, acc[kh * 4 + kw]);
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + 16 * u, r = p / Ho, ow = p - r * Ho;
+                const float* xr = sx + (2 * r) * Wp + 2 * ow;
+                acc[16] += g[u];
+#pragma unroll
+                for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 4; ++kw) {
+                        const float xv = xr[kh * Wp + kw];
+                        f4v& a = acc[kh * 4 + kw];
+                        a.x = fmaf(g[u].x, xv, a.x); a.y = fmaf(g[u].y, xv, a.y); a.z = fmaf(g[u].z, xv, a.z); a.w = fmaf(g[u].w, xv, a.w);
+                    }
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < 17; ++t) sh[threadIdx.x * 17 + t] = acc[t];
+    for (int o = 16; o < 64; o <<= 1)
+#pragma unroll
+        for (int t = 0; t < 17; ++t) {
+            acc[t].x += __shfl_xor(acc[t].x, o); acc[t].y += __shfl_xor(acc[t].y, o);
+            acc[t].z += __shfl_xor(acc[t].z, o); acc[t].w += __shfl_xor(acc[t].w, o);
+        }
+    if ((threadIdx.x & 63) < 16) {
+#pragma unroll
+        for (int t = 0; t < 17; ++t) {
+            sh[wave][q][0 * 17 + t] = acc[t].x; sh[wave][q][1 * 17 + t] = acc[t].y;
+            sh[wave][q][2 * 17 + t] = acc[t].z; sh[wave][q][3 * 17 + t] = acc[t].w;
+        }
+    }
     __syncthreads();
     float* out = partial + (size_t)blockIdx.x * (C * 17);
     for (int o = threadIdx.x; o < C * 17; o += 256) {
-        // output order: [C*16 weights (co*16+tap)] then [C biases]
-        float s = 0.f;
         int c, t;
-        if (o < C * 16) { c = o / 16; t = o % 16; } else { c = o - C * 16; t = 16; }
-        for (int k = 0; k < npl; ++k) s += sh[(k * C + c) * 17 + t];
-        out[o] = s;
+        if (o < C * 16) { c = o >> 4; t = o & 15; } else { c = o - C * 16; t = 16; }
+        const int g = c >> 2, j = (c & 3) * 17 + t;
+        out[o] = ((sh[0][g][j] + sh[1][g][j]) + sh[2][g][j]) + sh[3][g][j];
     }
 }
 void launch_conv1_wgrad(const float* dv, const float* x0, int n0, const float* x1, float* dW, float* db, float* partial,
                         int B, int S, int C, hipStream_t s) {
-    const int64_t total = (int64_t)B * (S / 2) * (S / 2);
-    int nch = 512;
-    int ppb = cdiv(total, nch);
-    ppb = ((ppb + 3) / 4) * 4;
-    nch = cdiv(total, ppb);
-    hipLaunchKernelGGL(k_conv1_wgrad, dim3(nch), dim3(256), 256 * 17 * sizeof(float), s, dv, x0, n0, x1, partial, B, S, C, ppb);
+    const int nstrips = B * (S / 2 / 4);
+    const int nch = nstrips < 1024 ? nstrips : 1024;
+    hipLaunchKernelGGL(k_conv1_wgrad, dim3(nch), dim3(256), 0, s, dv, x0, n0, x1, partial, S, nstrips);
     hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 17, 64)), dim3(1024), 0, s, partial, nch, C * 17, dW, C * 16, db);
 }
 
-// 16 lanes per image pixel, 4 channels each; dpre = dimg * (1 - img^2)
+// d(image) from dv, times tanh' -> d(pre-tanh).  A thread owns 4 channels of a column of 2x2 image
+// blocks: block (a, b) = image pixels (2a..2a+1, 2b..2b+1) needs dv rows a-1..a+1, cols b-1..b+1 and
+// every tap exactly once (ih = 2a: kh 1 -> oh a, kh 3 -> oh a-1; ih = 2a+1: kh 0 -> oh a+1, kh 2 -> oh a).
+// 16 channel lanes x 16 columns per block, RA block rows per thread (sliding 3-row window).
 __global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const float* __restrict__ dv, const float* __restrict__ W,
-                                                          const float* __restrict__ img, float* __restrict__ dpre, int B,
-                                                          int S, int C) {
-    extern __shared__ __attribute__((aligned(16))) float sW[];   // [16][C]
-    for (int i = threadIdx.x; i < 16 * C; i += 256) sW[i] = W[(i % C) * 16 + i / C];
-    __syncthreads();
-    const int Ho = S / 2, Q = C / 4;              // host guarantees Q == 16
-    const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int64_t pix = (int64_t)blockIdx.x * 16 + pl;
-    const bool live = pix < (int64_t)B * S * S;
-    float acc = 0.f;
-    if (live) {
-        const int iw = (int)(pix % S), ih = (int)((pix / S) % S), n = (int)(pix / ((int64_t)S * S));
-        const int kh0 = (ih + 1) & 1, kw0 = (iw + 1) & 1;
+                                                          const float* __restrict__ img, float* __restrict__ dpre, int S) {
+    constexpr int RA = 4, C = 64;
+    const int Ho = S >> 1, nbb = Ho >> 4, nba = Ho / RA;
+    const int q = threadIdx.x & 15, bl = threadIdx.x >> 4;
+    int bid = blockIdx.x;
+    const int b = (bid % nbb) * 16 + bl; bid /= nbb;
+    const int a0 = (bid % nba) * RA, n = bid / nba;
+    f4v w[16];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int kh = kh0 + 2 * a, oh = (ih + 1 - kh) >> 1;
-            if ((ih + 1 - kh) < 0 || oh >= Ho) continue;
+    for (int t = 0; t < 16; ++t)
+        w[t] = f4v{W[(q * 4 + 0) * 16 + t], W[(q * 4 + 1) * 16 + t], W[(q * 4 + 2) * 16 + t], W[(q * 4 + 3) * 16 + t]};
+    const float* base = dv + (size_t)n * Ho * Ho * C + q * 4;
+    f4v g[RA + 2][3];
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const int kw = kw0 + 2 * bb, ow = (iw + 1 - kw) >> 1;
-                if ((iw + 1 - kw) < 0 || ow >= Ho) continue;
-                const float4 g = *(const float4*)(dv + (((size_t)n * Ho + oh) * Ho + ow) * C + q * 4);
-                const float4 wv = *(const float4*)(sW + (kh * 4 + kw) * C + q * 4);
-                acc = fmaf(g.x, wv.x, acc); acc = fmaf(g.y, wv.y, acc);
-                acc = fmaf(g.z, wv.z, acc); acc = fmaf(g.w, wv.w, acc);
-            }
+    for (int r = 0; r < RA + 2; ++r) {
+        const int oh = a0 + r - 1, oc = clampi(oh, Ho - 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int ow = b + k - 1, wc = clampi(ow, Ho - 1);
+            const f4v t = ldg4(base + ((size_t)oc * Ho + wc) * C);
+            g[r][k] = (oh == oc && ow == wc) ? t : f4v{0.f, 0.f, 0.f, 0.f};
         }
     }
-    (void)Q;
-    acc += __shfl_xor(acc, 8, 16); acc += __shfl_xor(acc, 4, 16);
-    acc += __shfl_xor(acc, 2, 16); acc += __shfl_xor(acc, 1, 16);
-    if (live && q == 0) {
-        const float t = img[pix];
-        dpre[pix] = acc * (1.0f - t * t);
+#define DOT4(A, Wt, acc) acc = fmaf((A).x, (Wt).x, acc); acc = fmaf((A).y, (Wt).y, acc); acc = fmaf((A).z, (Wt).z, acc); acc = fmaf((A).w, (Wt).w, acc)
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        // g[r] = row a-1, g[r+1] = row a, g[r+2] = row a+1; columns 0,1,2 = b-1, b, b+1
+        float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+        // (2a, 2b): kh in {1: a, 3: a-1}, kw in {1: b, 3: b-1}
+        DOT4(g[r + 1][1], w[1 * 4 + 1], o00); DOT4(g[r + 1][0], w[1 * 4 + 3], o00);
+        DOT4(g[r][1], w[3 * 4 + 1], o00);     DOT4(g[r][0], w[3 * 4 + 3], o00);
+        // (2a, 2b+1): kw in {0: b+1, 2: b}
+        DOT4(g[r + 1][2], w[1 * 4 + 0], o01); DOT4(g[r + 1][1], w[1 * 4 + 2], o01);
+        DOT4(g[r][2], w[3 * 4 + 0], o01);     DOT4(g[r][1], w[3 * 4 + 2], o01);
+        // (2a+1, 2b): kh in {0: a+1, 2: a}
+        DOT4(g[r + 2][1], w[0 * 4 + 1], o10); DOT4(g[r + 2][0], w[0 * 4 + 3], o10);
+        DOT4(g[r + 1][1], w[2 * 4 + 1], o10); DOT4(g[r + 1][0], w[2 * 4 + 3], o10);
+        // (2a+1, 2b+1)
+        DOT4(g[r + 2][2], w[0 * 4 + 0], o11); DOT4(g[r + 2][1], w[0 * 4 + 2], o11);
+        DOT4(g[r + 1][2], w[2 * 4 + 0], o11); DOT4(g[r + 1][1], w[2 * 4 + 2], o11);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            o00 += __shfl_xor(o00, o, 16); o01 += __shfl_xor(o01, o, 16);
+            o10 += __shfl_xor(o10, o, 16); o11 += __shfl_xor(o11, o, 16);
+        }
+        if (q < 4) {
+            const float v = q == 0 ? o00 : (q == 1 ? o01 : (q == 2 ? o10 : o11));
+            const size_t pix = ((size_t)n * S + 2 * (a0 + r) + (q >> 1)) * S + 2 * b + (q & 1);
+            const float t = img[pix];
+            dpre[pix] = v * (1.0f - t * t);
+        }
     }
+#undef DOT4
 }
 void launch_conv1_dgrad_tanh(const float* dv, const float* W, const float* img, float* dpre, int B, int S, int C,
                              hipStream_t s) {
-    hipLaunchKernelGGL(k_conv1_dgrad_tanh, dim3(cdiv((int64_t)B * S * S, 16)), dim3(256), 16 * C * sizeof(float), s, dv, W,
-                       img, dpre, B, S, C);
+    (void)C;
+    const int Ho = S / 2;
+    hipLaunchKernelGGL(k_conv1_dgrad_tanh, dim3(B * (Ho / 4) * (Ho / 16)), dim3(256), 0, s, dv, W, img, dpre, S);
 }
 
 // =========================================================================================

@@ -560,17 +560,20 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     if (!k.has_z) launch_randn(c->z, (int64_t)B * c->latent, c->dev, 1, L.m);
     g_forward_pass(c, c->z, B, false, c->img, L.m);                  // G.eval(), no grad (train...py:314-315)
     L.join(L.a);
+    // siggan_step_begin: the G step's training forward depends on nothing the D step changes, so it
+    // runs on its own lane beside D(fake) and the D step's backward (after the eval forward above: it
+    // moves the BatchNorm running statistics and reuses the activation buffers; its own image / z /
+    // scratch).  It forks HERE but is enqueued after D(fake), whose kernels the dispatcher should see first.
+    hipEvent_t e_spec = nullptr;
+    if (k.spec_g) { e_spec = L.next(); (void)hipEventRecord(e_spec, L.m); }
+    d_forward_rows(c, c->img, B, B, drop, L.m, c->slab_k);           // D(fake) into rows [B, 2B)
+    launch_bce(c->logits, 2 * B, B, k.ls, 0.f, c->probs, c->dlogit, k.mt, 0, L.m);
     if (k.spec_g) {
-        // siggan_step_begin: the G step's training forward depends on nothing the D step changes, so it
-        // runs on its own lane beside the D step's backward (after the eval forward above: it moves the
-        // BatchNorm running statistics and reuses the activation buffers; its own image / z / scratch).
-        L.fork(c->s_c);
+        (void)hipStreamWaitEvent(c->s_c, e_spec, 0);
         if (!k.has_zg) launch_randn(c->z_g, (int64_t)B * c->latent, c->dev, 2, c->s_c);
         g_forward_pass(c, c->z_g, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2);
         (void)hipEventRecord(c->ev_gfwd, c->s_c);
     }
-    d_forward_rows(c, c->img, B, B, drop, L.m, c->slab_k);           // D(fake) into rows [B, 2B)
-    launch_bce(c->logits, 2 * B, B, k.ls, 0.f, c->probs, c->dlogit, k.mt, 0, L.m);
     d_backward_pass(c, L, c->real_stage, B, c->img, 2 * B, drop, true, false);
 }
 
