@@ -43,6 +43,7 @@ struct WgradArgs {
     const float* S;       // [B][Hs][Ws][Cs]   (small spatial)
     const float* L;       // [B][2Hs][2Ws][Cl] (large spatial)
     float* slab;          // [nsplit][Cs][16*Cl]
+    float* dw;            // result, torch layout: dw[(i*Cl + l)*16 + tap]
     int B, Cs, Cl;
     int lgHs, lgWs, lgCl;
     int K;                // B*Hs*Ws pixels
@@ -64,10 +65,9 @@ struct Prof {
 extern Prof* g_prof;
 
 void launch_gconv(const GConvArgs& a, hipStream_t st);
-// returns the number of K splits it used (slab must hold max_splits*Cs*16*Cl floats)
+// fills a.dw (through the slabs + k_wgrad_reduce when K is split); returns the number of K splits
+// (slab must hold max_splits*Cs*16*Cl floats)
 int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st);
-// dw[(s*Cl + l)*16 + tap] (+)= sum_z slab[z][s][tap*Cl + l]
-void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int Cs, int Cl, hipStream_t st);
 // torch layout (O,I,4,4) -> down pack [O][tap*I + i];  torch (I,O,4,4) -> up pack [4][O][t*I + i]
 void launch_pack_down(const float* w, float* wp, int O, int I, hipStream_t st);
 void launch_pack_up(const float* w, float* wp, int I, int O, hipStream_t st);

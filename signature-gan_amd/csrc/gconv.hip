@@ -17,6 +17,7 @@
 // t+1 are issued before the MFMAs of tile t, written to the other LDS buffer after them).
 #include "gconv.h"
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 namespace siggan {
 
@@ -33,10 +34,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 32>
 __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int KC = BK / 32;        // 16-byte chunks a thread stages per row and K-tile
     // LDS tiles are [row][k] with a row stride of 36 floats (= 4 * odd): a staged float4 is ONE
     // ds_write_b128 (8 lanes cover a row's 128 B), and a lane's MFMA operands for 4 consecutive
     // sub-steps are ONE conflict-free ds_read_b128 (the 16 lanes of a b128 group hit 16 distinct
@@ -102,15 +104,18 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
             a_step[p] = ok ? BK : 0;
         }
     };
-    f32x4 ra[PA], rb[PB];
+    f32x4 ra[PA][KC], rb[PB][KC];
     auto load_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            ra[p] = *reinterpret_cast<const f32x4*>(a_cur[p]);
+#pragma unroll
+            for (int q = 0; q < KC; ++q) ra[p][q] = *reinterpret_cast<const f32x4*>(a_cur[p] + 32 * q);   // (zero page: 256 B)
             a_cur[p] += a_step[p];
         }
 #pragma unroll
-        for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(wcur + (size_t)(32 * p) * Ktot);
+        for (int p = 0; p < PB; ++p)
+#pragma unroll
+            for (int q = 0; q < KC; ++q) rb[p][q] = *reinterpret_cast<const f32x4*>(wcur + (size_t)(32 * p) * Ktot + 32 * q);
         wcur += BK;
         if (++l_cc == (1 << lgcpt)) { l_cc = 0; ++l_tap; set_tap(); }
     };
@@ -118,9 +123,13 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
         float* dA = sA + buf * LD * BM + rloc * LD + kc * 4;
         float* dB = sB + buf * LD * BN + rloc * LD + kc * 4;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(dA + 32 * p * LD) = ra[p];
+        for (int p = 0; p < PA; ++p)
 #pragma unroll
-        for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(dB + 32 * p * LD) = rb[p];
+            for (int q = 0; q < KC; ++q) *reinterpret_cast<f32x4*>(dA + 32 * p * LD + 32 * q) = ra[p][q];
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+#pragma unroll
+            for (int q = 0; q < KC; ++q) *reinterpret_cast<f32x4*>(dB + 32 * p * LD + 32 * q) = rb[p][q];
     };
 
     f32x16 acc[TM][TN];
@@ -278,7 +287,7 @@ void Prof::clear() {
     recs.clear();
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BKT = 32>
 static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
     const int ncls = a.form == 0 ? 1 : 4;
@@ -286,9 +295,9 @@ static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     // algorithmic FLOPs = 2 * M * Co * (taps * Ci) per class (== 2 * conv MACs, padding taps included)
     if (g_prof) {
         g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, st);
-        hipExtLaunchKernelGGL((k_gconv<BM, BN, WM, WN>), grid, dim3(256), 0, st, g_prof->recs.back().e0, g_prof->recs.back().e1, 0, a);
+        hipExtLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT>), grid, dim3(256), 0, st, g_prof->recs.back().e0, g_prof->recs.back().e1, 0, a);
     } else {
-        hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT>), grid, dim3(256), 0, st, a);
     }
     if (nsplit > 1) {
         const int64_t total4 = (int64_t)a.B * a.Ho * a.Wo * a.Co / 4;
@@ -430,6 +439,21 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
 
 #undef WG_LOAD_TILE
 #undef WG_STORE_TILE
+    if (gridDim.z == 1 && a.dw) {
+        // a single split: un-permute straight into the torch layout, column j = tap*Cl + l -> dw[(row*Cl + l)*16 + tap]
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = j0 + wn * (32 * TN) + 32 * j + li;
+                    a.dw[((size_t)row * Cl + (col & (Cl - 1))) * 16 + (col >> a.lgCl)] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     float* const out = a.slab + (size_t)blockIdx.z * a.Cs * N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -441,6 +465,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
                 out[(size_t)row * N + j0 + wn * (32 * TN) + 32 * j + li] = acc[i][j][r];
         }
 }
+
+static void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int Cs, int Cl, hipStream_t st);
 
 int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
     // 64x64 tiles (one 32x32 accumulator per wave keeps the fp32 MFMA pipe full): many tiles,
@@ -467,30 +493,41 @@ int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
     } else {
         hipLaunchKernelGGL((k_wgrad<64, 64, 2, 2>), grid, dim3(256), 0, st, a);
     }
+    if (nsplit > 1) launch_wgrad_reduce(a.slab, a.dw, nsplit, a.Cs, 1 << a.lgCl, st);
     return nsplit;
 }
 
-__global__ void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
-                               int Cs, int lgCl) {
+// dw[(s*Cl + l)*16 + tap] = sum_z slab[z][s][tap*Cl + l].  A block owns 64 consecutive slab columns;
+// SL lanes per column each add every SL-th slab, then LDS combines the lanes in lane order (the sum
+// order is fixed by (nsplit, SL) alone: bitwise reproducible).
+__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
+                                                       int Cs, int lgCl) {
+    __shared__ float sh[16][64];
     const int N = 16 << lgCl, Cl = 1 << lgCl;
     const size_t total = (size_t)Cs * N;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(idx % N), s = (int)(idx / N);
-        float acc = 0.f;
-        for (int z = 0; z < nsplit; ++z) acc += slab[(size_t)z * total + idx];
-        const int tap = j >> lgCl, l = j & (Cl - 1);
-        dw[((size_t)s * Cl + l) * 16 + tap] = acc;
+    const int cl = threadIdx.x & 63, zl = threadIdx.x >> 6, SL = blockDim.x >> 6;
+    const size_t idx = (size_t)blockIdx.x * 64 + cl;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int z = zl; z < nsplit; z += SL) acc += slab[(size_t)z * total + idx];
+    if (SL > 1) {
+        sh[zl][cl] = acc;
+        __syncthreads();
+        if (zl != 0) return;
+        for (int k = 1; k < SL; ++k) acc += sh[k][cl];
     }
+    const int j = (int)(idx % N), s_ = (int)(idx / N);
+    const int tap = j >> lgCl, l = j & (Cl - 1);
+    dw[((size_t)s_ * Cl + l) * 16 + tap] = acc;
 }
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int Cs, int Cl, hipStream_t st) {
-    const size_t total = (size_t)Cs * 16 * Cl;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, slab, dw, nsplit, Cs, ilog2(Cl));
+static void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int Cs, int Cl, hipStream_t st) {
+    const size_t total = (size_t)Cs * 16 * Cl;                 // a multiple of 64 (Cs, Cl >= 32)
+    int SL = 1;
+    while (SL < 16 && SL < nsplit) SL *= 2;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(total / 64)), dim3(64 * SL), 0, st, slab, dw, nsplit, Cs, ilog2(Cl));
 }
 
 // ------------------------------------------------------------------------------------------
