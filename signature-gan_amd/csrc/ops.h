@@ -63,13 +63,17 @@ void launch_bn_train_stats(const float* y, int64_t R, int C, const float* gamma,
                            int perm_c0, float momentum, float eps, hipStream_t s);
 // a = relu(y*scale + shift)
 void launch_bn_relu(const float* y, float* a, int64_t R, int C, const float* bn, hipStream_t s);
-// backward through relu(BN(y)): da (in) -> dy (in place); dgamma/dbeta (torch order) written
-void launch_bn_bwd(float* da, const float* y, const float* a, int64_t R, int C, float* bn, float* partial,
+// backward through relu(BN(y)): da (in) -> dy (in place); dgamma/dbeta (torch order) written.  The relu mask is
+// re-derived from y and the layer's scale/shift (the forward's own expression), so the activation is not read.
+void launch_bn_bwd(float* da, const float* y, int64_t R, int C, float* bn, float* partial,
                    float* dgamma, float* dbeta, int perm_c0, hipStream_t s);
 
 // final 3x3 conv (C->1) + tanh, and its backward pieces.  act: [B][S][S][C] NHWC, img [B][S][S]
 void launch_final_fwd(const float* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s);
-void launch_final_dgrad(const float* dpre, const float* W, float* dact, int B, int S, int C, hipStream_t s);
+// backward of the last Generator block from dpre in one pass family: d(act) of the final conv (recomputed, never stored),
+// relu mask re-derived from y, BatchNorm statistics + apply -> dy; dgamma/dbeta written
+void launch_final_dgrad_bn_bwd(const float* dpre, const float* W, const float* y, float* dy, int B, int S, int C, float* bn,
+                               float* partial, float* dgamma, float* dbeta, hipStream_t s);
 void launch_final_wgrad(const float* dpre, const float* act, float* dW, float* db, float* partial, int B, int S,
                         int C, hipStream_t s);
 

@@ -189,19 +189,23 @@ __global__ __launch_bounds__(256) void k_colreduce(F f, int64_t R, int C, int cg
 
 // stage 2: a 1024-thread block finalizes 64 columns; 16 lanes add the chunk partials, LDS combines
 // the lanes in a fixed order (bitwise reproducible).
+template <int W = 64>
 __device__ __forceinline__ void gather2(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int C,
                                         float& s, float& q, float (*sh)[16][64]) {
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, nl = blockDim.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    // W column lanes x (blockDim / W) row lanes; the LDS block is used as [2][blockDim / W][W]
+    const int cl = threadIdx.x & (W - 1), rl = threadIdx.x / W, nl = blockDim.x / W;
+    const int c = blockIdx.x * W + cl;
+    float* const s0 = &sh[0][0][0];
+    float* const s1 = &sh[1][0][0];
     float a = 0.f, b = 0.f;
     if (c < C) {
 #pragma unroll 4
         for (int k = rl; k < nch; k += nl) { a += p0[(size_t)k * C + c]; if (p1) b += p1[(size_t)k * C + c]; }
     }
-    sh[0][rl][cl] = a; sh[1][rl][cl] = b;
+    s0[rl * W + cl] = a; s1[rl * W + cl] = b;
     __syncthreads();
     s = 0.f; q = 0.f;
-    for (int k = 0; k < nl; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
+    for (int k = 0; k < nl; ++k) { s += s0[k * W + cl]; q += s1[k * W + cl]; }
 }
 
 struct FSum {
@@ -217,12 +221,13 @@ struct FStats {   // shifted sums around the first row: robust single-pass varia
         s1.x = fmaf(d.x, d.x, s1.x); s1.y = fmaf(d.y, d.y, s1.y); s1.z = fmaf(d.z, d.z, s1.z); s1.w = fmaf(d.w, d.w, s1.w);
     }
 };
-struct FBnBwd {
-    const float4* da; const float4* y; const float4* a; const float4* bn;
+struct FBnBwd {   // relu mask re-derived from y (a > 0 <=> fma(y, scale, shift) > 0, k_bn_relu's own expression): a is not read
+    const float4* da; const float4* y; const float4* bn;
     __device__ void operator()(int64_t r, int c4, int C4, float4& s0, float4& s1) const {
         const size_t i = (size_t)r * C4 + c4;
-        const float4 g = da[i], yy = y[i], aa = a[i], mu = bn[2 * C4 + c4], rs = bn[3 * C4 + c4];
-        const float4 d = make_float4(aa.x > 0.f ? g.x : 0.f, aa.y > 0.f ? g.y : 0.f, aa.z > 0.f ? g.z : 0.f, aa.w > 0.f ? g.w : 0.f);
+        const float4 g = da[i], yy = y[i], sc = bn[c4], sf = bn[C4 + c4], mu = bn[2 * C4 + c4], rs = bn[3 * C4 + c4];
+        const float4 d = make_float4(fmaf(yy.x, sc.x, sf.x) > 0.f ? g.x : 0.f, fmaf(yy.y, sc.y, sf.y) > 0.f ? g.y : 0.f,
+                                     fmaf(yy.z, sc.z, sf.z) > 0.f ? g.z : 0.f, fmaf(yy.w, sc.w, sf.w) > 0.f ? g.w : 0.f);
         add4(s0, d);
         s1.x = fmaf(d.x, (yy.x - mu.x) * rs.x, s1.x); s1.y = fmaf(d.y, (yy.y - mu.y) * rs.y, s1.y);
         s1.z = fmaf(d.z, (yy.z - mu.z) * rs.z, s1.z); s1.w = fmaf(d.w, (yy.w - mu.w) * rs.w, s1.w);
@@ -262,6 +267,7 @@ void launch_bn_eval_affine(const float* gamma, const float* beta, const float* r
     hipLaunchKernelGGL(k_bn_eval_affine, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, rmean, rvar, bn, C, perm_c0, eps);
 }
 
+template <int W>
 __global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
                                const float* __restrict__ y, const float* __restrict__ gamma,
                                const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
@@ -269,10 +275,10 @@ __global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__
                                float eps) {
     __shared__ float sh[2][16][64];
     float s, q;
-    gather2(p0, p1, nch, C, s, q, sh);
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    gather2<W>(p0, p1, nch, C, s, q, sh);
+    const int c = blockIdx.x * W + (threadIdx.x & (W - 1));
     if (blockIdx.x == 0 && threadIdx.x == 0 && batches) batches[0] += 1;
-    if (threadIdx.x >= 64 || c >= C) return;
+    if (threadIdx.x >= W || c >= C) return;
     const float invR = 1.0f / (float)R;
     const float d = s * invR;
     const float mean = y[c] + d;
@@ -292,8 +298,12 @@ void launch_bn_train_stats(const float* y, int64_t R, int C, const float* gamma,
     const ColPlan pl = col_plan(R, C);
     float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
     hipLaunchKernelGGL((k_colreduce<FStats>), dim3(pl.cbx, pl.nch), dim3(256), 0, s, FStats{(const float4*)y}, R, C, pl.cg, pl.rows, p0, p1);
-    hipLaunchKernelGGL(k_bn_train_fin, dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, p1, pl.nch, R, C, y, gamma, beta, rmean,
-                       rvar, batches, bn, perm_c0, momentum, eps);
+    if (C <= 32)
+        hipLaunchKernelGGL(k_bn_train_fin<32>, dim3(cdiv(C, 32)), dim3(1024), 0, s, p0, p1, pl.nch, R, C, y, gamma, beta, rmean,
+                           rvar, batches, bn, perm_c0, momentum, eps);
+    else
+        hipLaunchKernelGGL(k_bn_train_fin<64>, dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, p1, pl.nch, R, C, y, gamma, beta, rmean,
+                           rvar, batches, bn, perm_c0, momentum, eps);
 }
 
 __global__ void k_bn_relu(const float4* __restrict__ y, float4* __restrict__ a, int64_t n4, int C4,
@@ -311,42 +321,48 @@ void launch_bn_relu(const float* y, float* a, int64_t R, int C, const float* bn,
                        (const float4*)bn);
 }
 
+template <int W>
 __global__ __launch_bounds__(1024) void k_bn_bwd_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
                              float* __restrict__ bn, float* __restrict__ dgamma, float* __restrict__ dbeta, int perm_c0) {
     __shared__ float sh[2][16][64];
     float s, q;
-    gather2(p0, p1, nch, C, s, q, sh);
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    if (threadIdx.x >= 64 || c >= C) return;
+    gather2<W>(p0, p1, nch, C, s, q, sh);
+    const int c = blockIdx.x * W + (threadIdx.x & (W - 1));
+    if (threadIdx.x >= W || c >= C) return;
     const int t = perm16(c, perm_c0);
     dbeta[t] = s; dgamma[t] = q;
     const float invR = 1.0f / (float)R;
     bn[4 * C + c] = s * invR; bn[5 * C + c] = q * invR;
 }
-__global__ void k_bn_bwd_apply(float4* __restrict__ da, const float4* __restrict__ y, const float4* __restrict__ a,
-                               int64_t n4, int C4, const float4* __restrict__ bn) {
+static void launch_bn_bwd_fin(const float* p0, const float* p1, int nch, int64_t R, int C, float* bn, float* dgamma,
+                              float* dbeta, int perm_c0, hipStream_t s) {
+    if (C <= 32) hipLaunchKernelGGL(k_bn_bwd_fin<32>, dim3(cdiv(C, 32)), dim3(1024), 0, s, p0, p1, nch, R, C, bn, dgamma, dbeta, perm_c0);
+    else hipLaunchKernelGGL(k_bn_bwd_fin<64>, dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, p1, nch, R, C, bn, dgamma, dbeta, perm_c0);
+}
+__global__ void k_bn_bwd_apply(float4* __restrict__ da, const float4* __restrict__ y, int64_t n4, int C4,
+                               const float4* __restrict__ bn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const int c = (int)(i % C4);
-    const float4 g = da[i], yy = y[i], aa = a[i];
-    const float4 sc = bn[c], mu = bn[2 * C4 + c], rs = bn[3 * C4 + c], c1 = bn[4 * C4 + c], c2 = bn[5 * C4 + c];
+    const float4 g = da[i], yy = y[i];
+    const float4 sc = bn[c], sf = bn[C4 + c], mu = bn[2 * C4 + c], rs = bn[3 * C4 + c], c1 = bn[4 * C4 + c], c2 = bn[5 * C4 + c];
     float4 o;
-    o.x = sc.x * ((aa.x > 0.f ? g.x : 0.f) - c1.x - (yy.x - mu.x) * rs.x * c2.x);
-    o.y = sc.y * ((aa.y > 0.f ? g.y : 0.f) - c1.y - (yy.y - mu.y) * rs.y * c2.y);
-    o.z = sc.z * ((aa.z > 0.f ? g.z : 0.f) - c1.z - (yy.z - mu.z) * rs.z * c2.z);
-    o.w = sc.w * ((aa.w > 0.f ? g.w : 0.f) - c1.w - (yy.w - mu.w) * rs.w * c2.w);
+    o.x = sc.x * ((fmaf(yy.x, sc.x, sf.x) > 0.f ? g.x : 0.f) - c1.x - (yy.x - mu.x) * rs.x * c2.x);
+    o.y = sc.y * ((fmaf(yy.y, sc.y, sf.y) > 0.f ? g.y : 0.f) - c1.y - (yy.y - mu.y) * rs.y * c2.y);
+    o.z = sc.z * ((fmaf(yy.z, sc.z, sf.z) > 0.f ? g.z : 0.f) - c1.z - (yy.z - mu.z) * rs.z * c2.z);
+    o.w = sc.w * ((fmaf(yy.w, sc.w, sf.w) > 0.f ? g.w : 0.f) - c1.w - (yy.w - mu.w) * rs.w * c2.w);
     da[i] = o;
 }
-void launch_bn_bwd(float* da, const float* y, const float* a, int64_t R, int C, float* bn, float* partial,
+void launch_bn_bwd(float* da, const float* y, int64_t R, int C, float* bn, float* partial,
                    float* dgamma, float* dbeta, int perm_c0, hipStream_t s) {
     const ColPlan pl = col_plan(R, C);
     float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
     hipLaunchKernelGGL((k_colreduce<FBnBwd>), dim3(pl.cbx, pl.nch), dim3(256), 0, s,
-                       FBnBwd{(const float4*)da, (const float4*)y, (const float4*)a, (const float4*)bn}, R, C, pl.cg, pl.rows, p0, p1);
-    hipLaunchKernelGGL(k_bn_bwd_fin, dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, p1, pl.nch, R, C, bn, dgamma, dbeta, perm_c0);
+                       FBnBwd{(const float4*)da, (const float4*)y, (const float4*)bn}, R, C, pl.cg, pl.rows, p0, p1);
+    launch_bn_bwd_fin(p0, p1, pl.nch, R, C, bn, dgamma, dbeta, perm_c0, s);
     const int64_t n4 = R * C / 4;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, s, (float4*)da, (const float4*)y,
-                       (const float4*)a, n4, C / 4, (const float4*)bn);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, s, (float4*)da, (const float4*)y, n4, C / 4,
+                       (const float4*)bn);
 }
 
 // =========================================================================================
@@ -363,7 +379,7 @@ __global__ void k_fc_pack(const float* __restrict__ W, float* __restrict__ Wt, i
 void launch_fc_pack(const float* W, float* Wt, int K, int C0, hipStream_t s) {
     hipLaunchKernelGGL(k_fc_pack, dim3(cdiv((int64_t)K * C0 * 16, 256)), dim3(256), 0, s, W, Wt, K, C0);
 }
-// one thread = one feature f' x 8 batch rows; z rows broadcast from LDS
+// one thread = one feature f' x 8 batch rows; z rows broadcast from LDS; 20 weight loads in flight
 __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, const float* __restrict__ Wt,
                                                 const float* __restrict__ b, float* __restrict__ y, int B, int K, int C0) {
     extern __shared__ float sz[];   // [8][K]
@@ -378,8 +394,19 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, con
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float w = Wt[(size_t)k * F + fp];
+    const float* wp = Wt + fp;
+    int k = 0;
+    for (; k + 20 <= K; k += 20) {
+        float w[20];
+#pragma unroll
+        for (int u = 0; u < 20; ++u) w[u] = wp[(size_t)(k + u) * F];
+#pragma unroll
+        for (int u = 0; u < 20; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(sz[j * K + k + u], w[u], acc[j]);
+    }
+    for (; k < K; ++k) {
+        const float w = wp[(size_t)k * F];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = fmaf(sz[j * K + k], w, acc[j]);
     }
@@ -391,24 +418,56 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, con
 void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s) {
     hipLaunchKernelGGL(k_fc_fwd, dim3(cdiv(C0 * 16, 256), cdiv(B, 8)), dim3(256), 8 * K * sizeof(float), s, z, Wt, b, y, B, K, C0);
 }
-__global__ void k_fc_wgrad(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dW,
+// dW[f][k] = sum_n dy[n][f'] * z[n][k],  db[f] = sum_n dy[n][f'].  A thread owns feature f' and a group of
+// FK latent columns: every dy value it loads feeds FK FMAs (z rows broadcast from LDS, 64 batch rows per
+// pass), instead of one load per FMA.
+static constexpr int FK = 8;
+__global__ __launch_bounds__(256) void k_fc_wgrad(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dW,
                            float* __restrict__ db, int B, int K, int C0) {
+    __shared__ float sz[64][FK];
     const int F = C0 * 16;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)(K + 1) * F) return;
-    const int fp = (int)(idx % F), k = (int)(idx / F);
-    const int f = (fp % C0) * 16 + fp / C0;
-    float acc = 0.f;
-    if (k < K) {
-        for (int n = 0; n < B; ++n) acc = fmaf(dy[(size_t)n * F + fp], z[(size_t)n * K + k], acc);
-        dW[(size_t)f * K + k] = acc;
-    } else {
-        for (int n = 0; n < B; ++n) acc += dy[(size_t)n * F + fp];
-        db[f] = acc;
+    const int fp = blockIdx.x * 256 + threadIdx.x, k0 = blockIdx.y * FK;
+    float acc[FK], sb = 0.f;
+#pragma unroll
+    for (int u = 0; u < FK; ++u) acc[u] = 0.f;
+    for (int n0 = 0; n0 < B; n0 += 64) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * FK; i += 256) {
+            const int n = n0 + i / FK, k = k0 + i % FK;
+            sz[i / FK][i % FK] = (n < B && k < K) ? z[(size_t)n * K + k] : 0.f;
+        }
+        __syncthreads();
+        if (fp < F) {
+            const int nn = B - n0 < 64 ? B - n0 : 64;
+            int n = 0;
+            for (; n + 8 <= nn; n += 8) {
+                float g[8];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) g[v] = dy[(size_t)(n0 + n + v) * F + fp];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    sb += g[v];
+#pragma unroll
+                    for (int u = 0; u < FK; ++u) acc[u] = fmaf(g[v], sz[n + v][u], acc[u]);
+                }
+            }
+            for (; n < nn; ++n) {
+                const float g = dy[(size_t)(n0 + n) * F + fp];
+                sb += g;
+#pragma unroll
+                for (int u = 0; u < FK; ++u) acc[u] = fmaf(g, sz[n][u], acc[u]);
+            }
+        }
     }
+    if (fp >= F) return;
+    const int f = (fp % C0) * 16 + fp / C0;
+#pragma unroll
+    for (int u = 0; u < FK; ++u)
+        if (k0 + u < K) dW[(size_t)f * K + k0 + u] = acc[u];
+    if (blockIdx.y == 0) db[f] = sb;
 }
 void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s) {
-    hipLaunchKernelGGL(k_fc_wgrad, dim3(cdiv((int64_t)(K + 1) * C0 * 16, 256)), dim3(256), 0, s, dy, z, dW, db, B, K, C0);
+    hipLaunchKernelGGL(k_fc_wgrad, dim3(cdiv(C0 * 16, 256), cdiv(K, FK)), dim3(256), 0, s, dy, z, dW, db, B, K, C0);
 }
 
 // =========================================================================================
@@ -473,17 +532,13 @@ void launch_final_fwd(const float* act, const float* W, const float* b, float* i
     hipLaunchKernelGGL(k_final_fwd, dim3(B * (S / 4) * (S / 32)), dim3(256), 0, s, act, W, b, img, S);
 }
 
-__global__ __launch_bounds__(256) void k_final_dgrad(const float* __restrict__ dpre, const float* __restrict__ W,
-                                                     float* __restrict__ dact, int S) {
-    constexpr int RY = 4, C = 32;
-    const int c4 = threadIdx.x & 7;
-    const StripId t = strip_of<RY>(blockIdx.x, S, threadIdx.x >> 3);
-    f4v w[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-        w[k] = f4v{W[(c4 * 4 + 0) * 9 + k], W[(c4 * 4 + 1) * 9 + k], W[(c4 * 4 + 2) * 9 + k], W[(c4 * 4 + 3) * 9 + k]};
+// d(act)[y][x][c] = sum_{kh,kw} dpre[y + 1 - kh][x + 1 - kw] * W[c][kh][kw], for the 4 channels of a lane.
+// The activation gradient is never stored: BatchNorm's backward of the last Generator block needs it
+// twice (statistics, then apply) and recomputing it from the 1-channel dpre is 36 FMAs against a
+// 33 MB round trip.  d[r][k] = dpre row (y0 - 1 + r), column (x - 1 + k), zero outside the image.
+template <int RY>
+__device__ __forceinline__ void load_dpre_strip(const float* __restrict__ dpre, const StripId& t, int S, float (&d)[RY + 2][3]) {
     const float* base = dpre + (size_t)t.n * S * S;
-    float d[RY + 2][3];
 #pragma unroll
     for (int r = 0; r < RY + 2; ++r) {
         const int yy = t.y0 + r - 1, yc = clampi(yy, S - 1);
@@ -494,23 +549,108 @@ __global__ __launch_bounds__(256) void k_final_dgrad(const float* __restrict__ d
             d[r][k] = (yy == yc && xx == xc) ? q : 0.f;
         }
     }
+}
+template <int RY>
+__device__ __forceinline__ f4v final_dact(const float (&d)[RY + 2][3], const f4v (&w)[9], int r) {
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < RY; ++r) {
-        f4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {
+            const float g = d[r + 2 - kh][2 - kw];
+            const f4v ww = w[kh * 3 + kw];
+            acc.x = fmaf(g, ww.x, acc.x); acc.y = fmaf(g, ww.y, acc.y); acc.z = fmaf(g, ww.z, acc.z); acc.w = fmaf(g, ww.w, acc.w);
+        }
+    return acc;
+}
+
+// Backward through [final conv] <- relu <- BatchNorm of the last Generator block, stage 1: per-channel
+// sums of dy_relu and dy_relu * xhat (the relu mask is re-derived from y: a > 0 <=> fma(y, scale, shift) > 0,
+// the forward's own expression).  One partial row per block; k_bn_bwd_fin adds the rows.
+__global__ __launch_bounds__(256) void k_final_bnbwd_reduce(const float* __restrict__ dpre, const float* __restrict__ W,
+                                                            const float* __restrict__ y, const float* __restrict__ bn,
+                                                            float* __restrict__ p0, float* __restrict__ p1, int S, int nstrips) {
+    constexpr int RY = 8, C = 32;
+    __shared__ f4v sh[2][4][8];
+    const int c4 = threadIdx.x & 7, wave = threadIdx.x >> 6;
+    f4v w[9];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {                 // dact[y][x] += dpre[y + 1 - kh][x + 1 - kw] * W[kh][kw]
-                const float g = d[r + 2 - kh][2 - kw];
-                const f4v ww = w[kh * 3 + kw];
-                acc.x = fmaf(g, ww.x, acc.x); acc.y = fmaf(g, ww.y, acc.y); acc.z = fmaf(g, ww.z, acc.z); acc.w = fmaf(g, ww.w, acc.w);
-            }
-        *reinterpret_cast<f4v*>(dact + (((size_t)t.n * S + t.y0 + r) * S + t.x) * C + c4 * 4) = acc;
+    for (int k = 0; k < 9; ++k)
+        w[k] = f4v{W[(c4 * 4 + 0) * 9 + k], W[(c4 * 4 + 1) * 9 + k], W[(c4 * 4 + 2) * 9 + k], W[(c4 * 4 + 3) * 9 + k]};
+    const f4v sc = ldg4(bn + c4 * 4), sf = ldg4(bn + C + c4 * 4), mu = ldg4(bn + 2 * C + c4 * 4), rs = ldg4(bn + 3 * C + c4 * 4);
+    f4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    for (int sid = blockIdx.x; sid < nstrips; sid += gridDim.x) {
+        const StripId t = strip_of<RY>(sid, S, threadIdx.x >> 3);
+        float d[RY + 2][3];
+        load_dpre_strip<RY>(dpre, t, S, d);
+        const float* ybase = y + (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
+        f4v yv[RY];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) yv[r] = ldg4(ybase + (size_t)r * S * C);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const f4v g = final_dact<RY>(d, w, r);
+            const f4v v = yv[r];
+            const f4v m = {fmaf(v.x, sc.x, sf.x) > 0.f ? g.x : 0.f, fmaf(v.y, sc.y, sf.y) > 0.f ? g.y : 0.f,
+                           fmaf(v.z, sc.z, sf.z) > 0.f ? g.z : 0.f, fmaf(v.w, sc.w, sf.w) > 0.f ? g.w : 0.f};
+            s0 += m;
+            s1.x = fmaf(m.x, (v.x - mu.x) * rs.x, s1.x); s1.y = fmaf(m.y, (v.y - mu.y) * rs.y, s1.y);
+            s1.z = fmaf(m.z, (v.z - mu.z) * rs.z, s1.z); s1.w = fmaf(m.w, (v.w - mu.w) * rs.w, s1.w);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        s0.x += __shfl_xor(s0.x, o); s0.y += __shfl_xor(s0.y, o); s0.z += __shfl_xor(s0.z, o); s0.w += __shfl_xor(s0.w, o);
+        s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
+    }
+    if ((threadIdx.x & 63) < 8) { sh[0][wave][c4] = s0; sh[1][wave][c4] = s1; }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const f4v a = ((sh[0][0][c4] + sh[0][1][c4]) + sh[0][2][c4]) + sh[0][3][c4];
+        const f4v b = ((sh[1][0][c4] + sh[1][1][c4]) + sh[1][2][c4]) + sh[1][3][c4];
+        *reinterpret_cast<f4v*>(p0 + (size_t)blockIdx.x * C + c4 * 4) = a;
+        *reinterpret_cast<f4v*>(p1 + (size_t)blockIdx.x * C + c4 * 4) = b;
     }
 }
-void launch_final_dgrad(const float* dpre, const float* W, float* dact, int B, int S, int C, hipStream_t s) {
-    (void)C;
-    hipLaunchKernelGGL(k_final_dgrad, dim3(B * (S / 4) * (S / 32)), dim3(256), 0, s, dpre, W, dact, S);
+// stage 2 (after k_bn_bwd_fin): dy = scale * (dy_relu - c1 - xhat * c2), written to dy[B][S][S][C]
+__global__ __launch_bounds__(256) void k_final_bnbwd_apply(const float* __restrict__ dpre, const float* __restrict__ W,
+                                                           const float* __restrict__ y, const float* __restrict__ bn,
+                                                           float* __restrict__ dy, int S) {
+    constexpr int RY = 4, C = 32;
+    const int c4 = threadIdx.x & 7;
+    const StripId t = strip_of<RY>(blockIdx.x, S, threadIdx.x >> 3);
+    f4v w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        w[k] = f4v{W[(c4 * 4 + 0) * 9 + k], W[(c4 * 4 + 1) * 9 + k], W[(c4 * 4 + 2) * 9 + k], W[(c4 * 4 + 3) * 9 + k]};
+    const f4v sc = ldg4(bn + c4 * 4), sf = ldg4(bn + C + c4 * 4), mu = ldg4(bn + 2 * C + c4 * 4), rs = ldg4(bn + 3 * C + c4 * 4);
+    const f4v c1 = ldg4(bn + 4 * C + c4 * 4), c2 = ldg4(bn + 5 * C + c4 * 4);
+    float d[RY + 2][3];
+    load_dpre_strip<RY>(dpre, t, S, d);
+    const size_t o0 = (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
+    f4v yv[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) yv[r] = ldg4(y + o0 + (size_t)r * S * C);
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const f4v g = final_dact<RY>(d, w, r);
+        const f4v v = yv[r];
+        f4v o;
+        o.x = sc.x * ((fmaf(v.x, sc.x, sf.x) > 0.f ? g.x : 0.f) - c1.x - (v.x - mu.x) * rs.x * c2.x);
+        o.y = sc.y * ((fmaf(v.y, sc.y, sf.y) > 0.f ? g.y : 0.f) - c1.y - (v.y - mu.y) * rs.y * c2.y);
+        o.z = sc.z * ((fmaf(v.z, sc.z, sf.z) > 0.f ? g.z : 0.f) - c1.z - (v.z - mu.z) * rs.z * c2.z);
+        o.w = sc.w * ((fmaf(v.w, sc.w, sf.w) > 0.f ? g.w : 0.f) - c1.w - (v.w - mu.w) * rs.w * c2.w);
+        *reinterpret_cast<f4v*>(dy + o0 + (size_t)r * S * C) = o;
+    }
+}
+void launch_final_dgrad_bn_bwd(const float* dpre, const float* W, const float* y, float* dy, int B, int S, int C, float* bn,
+                               float* partial, float* dgamma, float* dbeta, hipStream_t s) {
+    const int nstrips = B * (S / 4) * (S / 32), nstrips8 = nstrips / 2;          // apply: 4-row strips, reduce: 8-row strips
+    const int nch = nstrips8 < 1024 ? nstrips8 : 1024;
+    float* p0 = partial; float* p1 = partial + (size_t)nch * C;
+    hipLaunchKernelGGL(k_final_bnbwd_reduce, dim3(nch), dim3(256), 0, s, dpre, W, y, bn, p0, p1, S, nstrips8);
+    launch_bn_bwd_fin(p0, p1, nch, (int64_t)B * S * S, C, bn, dgamma, dbeta, 0, s);
+    hipLaunchKernelGGL(k_final_bnbwd_apply, dim3(nstrips), dim3(256), 0, s, dpre, W, y, bn, dy, S);
 }
 
 // dW[c][kh][kw] = sum act[n][y][x][c] * dpre[n][y - kh + 1][x - kw + 1];  db = sum dpre.

@@ -496,11 +496,14 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     const int Lg = c->Lg, S = c->S;
     L.fork(L.b);
     launch_final_wgrad(c->dpre, c->g_a[Lg], GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), c->partial_b, B, S, c->gC[Lg], L.b);
-    launch_final_dgrad(c->dpre, GP(c, gi_fin_w(c)), c->g_da[Lg], B, S, c->gC[Lg], L.m);
     for (int l = Lg; l >= 1; --l) {
         const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
         const int64_t R = (int64_t)B * Ho * Ho;
-        launch_bn_bwd(c->g_da[l], c->g_y[l], c->g_a[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m);
+        if (l == Lg)     // final conv's input-gradient folded into this block's BatchNorm backward
+            launch_final_dgrad_bn_bwd(c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
+                                      GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
+        else
+            launch_bn_bwd(c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m);
         L.fork(L.a);                                       // dy[l] is complete on m here
         // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
         WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
@@ -515,7 +518,7 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
         launch_gconv(a, L.m);
     }
-    launch_bn_bwd(c->g_da[0], c->fc_y, c->g_a[0], B, c->F, c->g_bn[0], c->partial, GG(c, gi_bn0_w()), GG(c, gi_bn0_b()),
+    launch_bn_bwd(c->g_da[0], c->fc_y, B, c->F, c->g_bn[0], c->partial, GG(c, gi_bn0_w()), GG(c, gi_bn0_b()),
                   c->gC[0], L.m);
     launch_fc_wgrad(c->g_da[0], z, GG(c, gi_fc_w()), GG(c, gi_fc_b()), B, c->latent, c->gC[0], L.m);
     L.join(L.a); L.join(L.b);
