@@ -105,12 +105,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # The loop hands each step the batch of the step after it as well (a prefetching loader has it):
+    # that batch's D(real) forward then runs beside this step's Generator backward (siggan_stage_real).
+    # Every step still does one D(real) forward -- for its successor instead of for itself.
     for _ in range(args.warmup):
-        dp.step(real)
+        dp.step(real, next_real=real)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dp.step(real)
+        dp.step(real, next_real=real)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -127,7 +130,7 @@ def main():
         eng.set_mode(graph=False, overlap=False)
         eng.prof_enable(True)
         for _ in range(args.steps):
-            dp.step(real) if world == 1 else (eng.d_step(real, sync=False), eng.g_step(BATCH, sync=False))
+            dp.step(real, next_real=real) if world == 1 else (eng.d_step(real, sync=False), eng.g_step(BATCH, sync=False))
         recs = eng.prof_read()
         eng.prof_enable(False)
         eng.set_mode(graph=False, overlap=not args.serialize)

@@ -167,6 +167,15 @@ int siggan_d_grads(siggan_ctx *ctx, const float *real_dev, int32_t batch, const 
 int siggan_step_begin(siggan_ctx *ctx, const float *real_dev, int32_t batch, const float *z_dev,
                       const float *masks_dev, const float *zg_dev, const siggan_hyper *hp,
                       float *metrics_dev, void *stream);
+/* Software-pipelining across steps: hands the library the real batch of the NEXT D step (copied, ordered
+ * on `stream`; the loop of GANTrainer.train_epoch, train_vanilla_gan_signatures.py:378-405, knows it one
+ * iteration early).  Call it after siggan_d_apply and before siggan_g_grads: that siggan_g_grads then
+ * runs the staged batch's D(real) forward (discriminator weights are final by then) on its own lane beside
+ * the Generator backward.  The next siggan_d_grads / siggan_step_begin consumes the staged batch when
+ * called with real_dev = NULL (a non-NULL real_dev discards it).  Results are bit-identical to the
+ * un-staged sequence as long as exactly one siggan_g_apply lies in between; without SIGGAN_MODE_OVERLAP
+ * (or under graph replay) the staged batch is simply used as the real batch. */
+int siggan_stage_real(siggan_ctx *ctx, const float *real_dev, int32_t batch, void *stream);
 int siggan_d_apply(siggan_ctx *ctx, const siggan_hyper *hp, float *metrics_dev, float *metrics_host,
                    void *stream);
 int siggan_g_grads(siggan_ctx *ctx, int32_t batch, const float *z_dev, const siggan_hyper *hp,

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "siggan_g_step": (C.c_int, [_P, _I32, _P, C.POINTER(Hyper), _P, _P, _P]),
     "siggan_d_grads": (C.c_int, [_P, _P, _I32, _P, _P, C.POINTER(Hyper), _P, _P]),
     "siggan_step_begin": (C.c_int, [_P, _P, _I32, _P, _P, _P, C.POINTER(Hyper), _P, _P]),
+    "siggan_stage_real": (C.c_int, [_P, _P, _I32, _P]),
     "siggan_d_apply": (C.c_int, [_P, C.POINTER(Hyper), _P, _P, _P]),
     "siggan_g_grads": (C.c_int, [_P, _I32, _P, C.POINTER(Hyper), _P, _P]),
     "siggan_g_apply": (C.c_int, [_P, C.POINTER(Hyper), _P, _P, _P]),

@@ -21,7 +21,9 @@ struct DevState {
 // ---- RNG (Philox4x32-10, counter = (index, stream, call counter)) --------------------------
 void launch_randn(float* out, int64_t n, const DevState* st, uint32_t stream_id, hipStream_t s);
 // out = u < keep ? 1/keep : 0
-void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uint32_t stream_id, hipStream_t s);
+// elements [elem0, elem0 + n) of the stream's table (elem0 % 4 == 0), drawn at counter rng_ctr + ctr_add
+void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uint32_t stream_id, hipStream_t s,
+                      int64_t elem0 = 0, uint32_t ctr_add = 0);
 // out = mask * (1/keep)
 void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, hipStream_t s);
 void launch_tick(DevState* st, hipStream_t s);

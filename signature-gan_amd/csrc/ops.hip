@@ -25,8 +25,8 @@ __device__ __forceinline__ uint4 philox(uint4 c, uint2 k) {
 }
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
-__device__ __forceinline__ uint4 draw(const DevState* st, uint64_t idx, uint32_t stream_id) {
-    const unsigned long long ctr = st->rng_ctr, seed = st->seed;
+__device__ __forceinline__ uint4 draw(const DevState* st, uint64_t idx, uint32_t stream_id, uint32_t ctr_add = 0) {
+    const unsigned long long ctr = st->rng_ctr + ctr_add, seed = st->seed;
     return philox(make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), stream_id, (uint32_t)ctr),
                   make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(ctr >> 32)));
 }
@@ -41,10 +41,10 @@ __global__ void k_randn(float* __restrict__ out, int64_t n, const DevState* __re
     for (int j = 0; j < 4 && t * 4 + j < n; ++j) out[t * 4 + j] = v[j];
 }
 __global__ void k_dropnoise(float* __restrict__ out, int64_t n, float keep, float inv, const DevState* __restrict__ st,
-                            uint32_t sid) {
+                            uint32_t sid, int64_t t0, uint32_t ctr_add) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t * 4 >= n) return;
-    const uint4 r = draw(st, (uint64_t)t, sid);
+    const uint4 r = draw(st, (uint64_t)(t0 + t), sid, ctr_add);
     const uint32_t x[4] = {r.x, r.y, r.z, r.w};
     for (int j = 0; j < 4 && t * 4 + j < n; ++j) out[t * 4 + j] = u01(x[j]) < keep ? inv : 0.f;
 }
@@ -57,8 +57,10 @@ __global__ void k_tick(DevState* st) { st->rng_ctr += 1; }
 void launch_randn(float* out, int64_t n, const DevState* st, uint32_t sid, hipStream_t s) {
     hipLaunchKernelGGL(k_randn, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, out, n, st, sid);
 }
-void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uint32_t sid, hipStream_t s) {
-    hipLaunchKernelGGL(k_dropnoise, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, out, n, keep, 1.0f / keep, st, sid);
+void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uint32_t sid, hipStream_t s, int64_t elem0,
+                      uint32_t ctr_add) {
+    hipLaunchKernelGGL(k_dropnoise, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, out, n, keep, 1.0f / keep, st, sid, elem0 / 4,
+                       ctr_add);
 }
 void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, hipStream_t s) {
     hipLaunchKernelGGL(k_mask_to_noise, dim3(cdiv(n, 256)), dim3(256), 0, s, mask, out, n, 1.0f / keep);

@@ -43,13 +43,13 @@ static const int MAXL = 6;
 static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 struct PhaseKey {
-    int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg;
+    int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg, pre_real;
     float* mt;   // where the phase writes its metrics (caller's buffer, or the workspace one)
     double lr, beta1, beta2, eps;
     float ls, clip, gs;
     bool operator==(const PhaseKey& o) const {
         return phase == o.phase && B == o.B && has_z == o.has_z && has_masks == o.has_masks && g_dirty == o.g_dirty &&
-               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
+               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && pre_real == o.pre_real && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
                clip == o.clip && gs == o.gs;
     }
 };
@@ -74,7 +74,7 @@ struct siggan_ctx {
     float *d_a[MAXL + 1], *d_dv[MAXL + 1], *d_noise[MAXL + 1];
     float *logits, *probs, *dlogit;
     float *g_up[MAXL + 1], *g_dn[MAXL + 1], *d_dn[MAXL + 1], *d_up[MAXL + 1], *wcp;
-    float *slab, *slab_k, *slab_k2, *partial, *partial_b, *partial_c, *z_g, *img_g, *metrics, *op_pack, *zeros, *wfc_t, *real_stage, *mask_stage;
+    float *slab, *slab_k, *slab_k2, *partial, *partial_b, *partial_c, *z_g, *img_g, *metrics, *op_pack, *zeros, *wfc_t, *real_stage, *real_next, *mask_stage;
     int64_t slab_floats, slab_k_floats;
     DevState* dev;
     // last *_grads call (for *_apply)
@@ -84,7 +84,9 @@ struct siggan_ctx {
     static constexpr int NEV = 96;
     int mode;
     hipStream_t s_m, s_a, s_b, s_c;
-    hipEvent_t ev_gfwd;
+    hipEvent_t ev_gfwd, ev_dreal;
+    int staged_B;        // batch of a real batch staged for the NEXT D step by siggan_stage_real (0: none)
+    int dreal_B;         // batch whose D(real) forward siggan_g_grads already enqueued on lane c (0: none)
     int zg_stash;        // batch of an explicit G-step z handed to siggan_step_begin when the forward was not pipelined
     int g_fwd_pending;   // batch of a Generator training forward already enqueued by siggan_step_begin (0: none)
     hipEvent_t ev[NEV], ev_bridge[2];
@@ -213,6 +215,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->z_g, Bm * c->latent);
         carve(&c->img_g, Bm * c->S * c->S);
         carve(&c->real_stage, Bm * c->S * c->S);
+        carve(&c->real_next, Bm * c->S * c->S);
         { int64_t sumC = 0; for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l]; carve(&c->mask_stage, 2 * Bm * sumC); }
         carve(&c->metrics, SIGGAN_M_COUNT);
         carve(&c->op_pack, (int64_t)512 * 512 * 16);
@@ -239,6 +242,8 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->s_b, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->s_c, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_gfwd, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_dreal, hipEventDisableTiming));
+    c->staged_B = c->dreal_B = 0;
     c->g_fwd_pending = 0;
     c->zg_stash = 0;
     for (int i = 0; i < siggan_ctx::NEV; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
@@ -290,12 +295,13 @@ extern "C" int siggan_bind(siggan_ctx* c, const siggan_storage* st) {
     for (const void* p : all)
         if (((uintptr_t)p & 15) != 0) return fail(SIGGAN_E_INVALID, "siggan_bind: arenas must be 16-byte aligned");
     c->st = *st;
-    c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0;
+    c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0; c->staged_B = c->dreal_B = 0;
     return SIGGAN_OK;
 }
 extern "C" int siggan_params_changed(siggan_ctx* c) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     c->g_dirty = c->d_dirty = true;
+    c->dreal_B = 0;                    // a D(real) forward started ahead of time used the old weights
     return SIGGAN_OK;
 }
 extern "C" int siggan_seed(siggan_ctx* c, uint64_t seed, uint64_t offset) {
@@ -303,6 +309,7 @@ extern "C" int siggan_seed(siggan_ctx* c, uint64_t seed, uint64_t offset) {
     HIPCHK(hipSetDevice(c->cfg.device));
     unsigned long long v[2] = {seed, offset};
     HIPCHK(hipMemcpy(c->dev, v, sizeof v, hipMemcpyHostToDevice));   // seed, rng_ctr are the first two fields
+    c->dreal_B = 0;                    // its dropout tables were drawn from the old stream
     return SIGGAN_OK;
 }
 
@@ -524,7 +531,9 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     L.join(L.a); L.join(L.b);
 }
 
-static void make_noise(siggan_ctx* c, const float* masks, int B, int passes, hipStream_t s) {
+// dropout multiplier tables of passes [p0, p1) (pass 0 = rows [0,B) = D(real), pass 1 = rows [B,2B) = D(fake)).
+// ctr_add: draw as if the step counter were that much further (a pass generated ahead of its step).
+static void make_noise(siggan_ctx* c, const float* masks, int B, int p0, int p1, hipStream_t s, uint32_t ctr_add = 0) {
     const float keep = 1.0f - c->cfg.dropout;
     int64_t sumC = 0;
     for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l];
@@ -532,10 +541,10 @@ static void make_noise(siggan_ctx* c, const float* masks, int B, int passes, hip
     for (int l = 1; l <= c->Ld; ++l) {
         const int64_t n = (int64_t)B * c->dC[l];
         if (masks) {
-            for (int p = 0; p < passes; ++p)
+            for (int p = p0; p < p1; ++p)
                 launch_mask_to_noise(masks + (int64_t)p * B * sumC + (int64_t)B * pre, c->d_noise[l] + p * n, n, keep, s);
         } else {
-            launch_dropnoise(c->d_noise[l], n * passes, keep, c->dev, 16 + l, s);
+            launch_dropnoise(c->d_noise[l] + p0 * n, n * (p1 - p0), keep, c->dev, 16 + l, s, p0 * n, ctr_add);
         }
         pre += c->dC[l];
     }
@@ -556,8 +565,12 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const bool drop = c->cfg.dropout > 0.f;
     L.fork(L.a);                                                     // lane a: D's packs, dropout tables, D(real)
     repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
-    if (drop) make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, 2, L.a);
-    d_forward_rows(c, c->real_stage, 0, B, drop, L.a, c->slab_k2);   // D(real) beside the Generator (train...py:309)
+    if (k.pre_real)      // staged batch -> this step's real batch (the D backward reads it again)
+        (void)hipMemcpyAsync(c->real_stage, c->real_next, (size_t)B * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, L.a);
+    if (drop) make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, k.pre_real == 2 ? 1 : 0, 2, L.a);
+    // D(real) beside the Generator (train...py:309) -- unless the previous siggan_g_grads already ran it
+    // (siggan_stage_real) beside its Generator backward; then bce only has to wait for that lane
+    if (k.pre_real != 2) d_forward_rows(c, c->real_stage, 0, B, drop, L.a, c->slab_k2);
     if (!k.has_z) launch_randn(c->z, (int64_t)B * c->latent, c->dev, 1, L.m);
     g_forward_pass(c, c->z, B, false, c->img, L.m);                  // G.eval(), no grad (train...py:314-315)
     L.join(L.a);
@@ -568,6 +581,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     hipEvent_t e_spec = nullptr;
     if (k.spec_g) { e_spec = L.next(); (void)hipEventRecord(e_spec, L.m); }
     d_forward_rows(c, c->img, B, B, drop, L.m, c->slab_k);           // D(fake) into rows [B, 2B)
+    if (k.pre_real == 2) (void)hipStreamWaitEvent(L.m, c->ev_dreal, 0);
     launch_bce(c->logits, 2 * B, B, k.ls, 0.f, c->probs, c->dlogit, k.mt, 0, L.m);
     if (k.spec_g) {
         (void)hipStreamWaitEvent(c->s_c, e_spec, 0);
@@ -596,6 +610,17 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     d_forward_rows(c, img, 0, B, false, L.m, c->slab_k);             // D.eval(): dropout off (train...py:350)
     launch_bce(c->logits, B, B, 1.0f, 1.0f, c->probs, c->dlogit, k.mt, 1, L.m);
     d_backward_pass(c, L, img, B, img, B, false, false, true);       // through D into the image; no D weight grads
+    if (k.pre_real) {
+        // siggan_stage_real: the NEXT D step's D(real) forward needs the Discriminator as it is now (its
+        // update is behind us) and the activation rows this step is done with: run it on lane c beside the
+        // Generator backward.  Its dropout tables are drawn for the step counter that step will see (+1:
+        // the Generator update in between ticks once).
+        const bool drop = c->cfg.dropout > 0.f;
+        L.fork(c->s_c);
+        if (drop) make_noise(c, nullptr, B, 0, 1, c->s_c, 1);
+        d_forward_rows(c, c->real_next, 0, B, drop, c->s_c, c->slab_k2);
+        (void)hipEventRecord(c->ev_dreal, c->s_c);
+    }
     g_backward_pass(c, L, zg, B);
 }
 
@@ -713,7 +738,8 @@ extern "C" int siggan_d_forward(siggan_ctx* c, const float* x_dev, int32_t batch
     repack(c, s, s, c->g_dirty, c->d_dirty);
     c->g_dirty = c->d_dirty = false;
     const bool drop = training != 0 && c->cfg.dropout > 0.f;
-    if (drop) { if (!masks_dev) launch_tick(c->dev, s); make_noise(c, masks_dev, batch, 1, s); }
+    if (drop) { if (!masks_dev) launch_tick(c->dev, s); make_noise(c, masks_dev, batch, 0, 1, s); }
+    c->dreal_B = 0;                    // the activation rows of a D(real) forward started ahead of time are overwritten
     d_forward_rows(c, x_dev, 0, batch, drop, s, c->slab_k);
     if (probs_dev) launch_bce(c->logits, batch, batch, 0.f, 0.f, probs_dev, nullptr, nullptr, 0, s);
     if (features_dev) launch_cls_features(c->d_a[c->Ld], features_dev, batch, c->dC[c->Ld], s);
@@ -726,7 +752,8 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     int rc = check_call(c, batch);
     if (rc) return rc;
     if ((rc = check_hyper(hp))) return rc;
-    if (!real_dev) return fail(SIGGAN_E_INVALID, "null real batch");
+    if (!real_dev && c->staged_B != batch)
+        return fail(SIGGAN_E_INVALID, "null real batch (and no batch of %d images staged by siggan_stage_real)", batch);
     if (!c->st.d_grads) return fail(SIGGAN_E_STATE, "gradient arena was not bound");
     if (c->g_fwd_pending) return fail(SIGGAN_E_STATE, "siggan_step_begin must be followed by siggan_g_grads before the next D step");
     // the speculative forward needs its own lane: without overlap (or under graph replay) it is skipped
@@ -735,7 +762,10 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     const int B = batch;
     const size_t img_bytes = (size_t)B * c->S * c->S * sizeof(float);
     // stage the caller's tensors into fixed workspace slots (captured phases must see fixed addresses)
-    if (real_dev != c->real_stage) HIPCHK(hipMemcpyAsync(c->real_stage, real_dev, img_bytes, hipMemcpyDeviceToDevice, s));
+    int pre_real = 0;                          // 1: the staged batch is this step's real batch; 2: and its D(real) forward is done
+    if (!real_dev) pre_real = (c->dreal_B == B && !masks_dev) ? 2 : 1;
+    else if (real_dev != c->real_stage) HIPCHK(hipMemcpyAsync(c->real_stage, real_dev, img_bytes, hipMemcpyDeviceToDevice, s));
+    c->staged_B = c->dreal_B = 0;
     if (z_dev && z_dev != c->z) HIPCHK(hipMemcpyAsync(c->z, z_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     int64_t sumC = 0;
     for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l];
@@ -744,11 +774,20 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     c->zg_stash = (!spec_g && zg_dev) ? B : 0;
     PhaseKey k = make_key(c, 0, B, z_dev != nullptr, masks_dev != nullptr, hp, metrics_dev);
     c->metrics_last = k.mt;
-    k.spec_g = spec_g; k.has_zg = spec_g && zg_dev != nullptr;
+    k.spec_g = spec_g; k.has_zg = spec_g && zg_dev != nullptr; k.pre_real = pre_real;
     if ((rc = run_phase(c, k, s))) return rc;
     c->g_dirty = c->d_dirty = false;
     if (spec_g) { c->g_fwd_pending = B; c->g_dirty = true; }   // running statistics moved
     c->pending = 1;
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_stage_real(siggan_ctx* c, const float* real_dev, int32_t batch, void* stream) {
+    int rc = check_call(c, batch);
+    if (rc) return rc;
+    if (!real_dev) return fail(SIGGAN_E_INVALID, "null real batch");
+    HIPCHK(hipMemcpyAsync(c->real_next, real_dev, (size_t)batch * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    c->staged_B = batch; c->dreal_B = 0;
     return SIGGAN_OK;
 }
 
@@ -812,7 +851,11 @@ extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, 
     PhaseKey k = make_key(c, 1, B, z_dev != nullptr, false, hp, metrics_dev);
     c->metrics_last = k.mt;
     k.spec_g = spec;
+    // a staged next batch: start its D(real) forward beside this Generator backward (own lane: eager overlap mode only)
+    k.pre_real = c->staged_B == B && c->dreal_B == 0 && (c->mode & SIGGAN_MODE_OVERLAP) != 0 && (c->mode & SIGGAN_MODE_GRAPH) == 0 &&
+                 g_prof == nullptr && c->pending == 0;
     if ((rc = run_phase(c, k, s))) return rc;
+    if (k.pre_real) c->dreal_B = B;
     c->g_fwd_pending = 0;
     c->d_dirty = false;
     c->g_dirty = true;                 // the training forward moved the BatchNorm running statistics

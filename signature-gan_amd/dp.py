@@ -50,11 +50,15 @@ class DataParallelStep:
                           e.d_exp_avg, e.d_exp_avg_sq, e.g_adam_steps, e.d_adam_steps])
         e.params_changed()
 
-    def step(self, real_local, z_d=None, z_g=None, masks=None, sync=False):
+    def step(self, real_local, z_d=None, z_g=None, masks=None, sync=False, next_real=None):
+        """next_real: this rank's shard of the FOLLOWING step's real batch, when the loop already holds it
+        (a prefetching loader does): its D(real) forward then runs beside this step's Generator backward."""
         e, hp, inv = self.e, self.hp, 1.0 / self.world
         e.step_begin(real_local, z_d, masks, z_g, hp["ls"])       # D grads + the G step's forward beside them
         allreduce_sum_(e.d_grads)
         dm = e.d_apply(hp["lr_d"], hp["beta1"], hp["beta2"], clip=hp["clip"], grad_scale=inv, sync=sync)
+        if next_real is not None:
+            e.stage_real(next_real)
         e.g_compute_grads(real_local.shape[0])
         allreduce_sum_(e.g_grads)
         gm = e.g_apply(hp["lr_g"], hp["beta1"], hp["beta2"], clip=hp["clip"], grad_scale=inv, sync=sync)

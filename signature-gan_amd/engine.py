@@ -209,8 +209,25 @@ class Engine:
             raise ValueError(f"noise must be ({b}, {self.latent_dim})")
         masks = self._masks(masks, b, 2)
         hp = self._hyper(0.0, 0.5, 0.999, label_smoothing=label_smoothing)
+        self._staged = None
         _lib.check(self.lib.siggan_d_grads(self._h, _ptr(real), b, _ptr(z), _ptr(masks), C.byref(hp), _ptr(self.metrics),
                                            self._stream()))
+
+    def stage_real(self, next_real):
+        """Hand over the NEXT step's real batch (siggan_stage_real): call between d_apply and g_compute_grads;
+        that g_compute_grads runs the batch's D(real) forward beside the Generator backward, and the next
+        step_begin / train_step given the same (unmodified) tensor picks it up.  Results do not change."""
+        next_real = _f32(next_real, self.device, "real_images")
+        s = self.image_size
+        if next_real.dim() != 4 or tuple(next_real.shape[1:]) != (1, s, s):
+            raise ValueError(f"real_images must be (B, 1, {s}, {s}), got {tuple(next_real.shape)}")
+        self._check_batch(next_real.shape[0])
+        _lib.check(self.lib.siggan_stage_real(self._h, _ptr(next_real), next_real.shape[0], self._stream()))
+        self._staged = (next_real.data_ptr(), next_real._version, tuple(next_real.shape))
+
+    def _take_staged(self, real):
+        st, self._staged = getattr(self, "_staged", None), None
+        return st is not None and st == (real.data_ptr(), real._version, tuple(real.shape))
 
     def step_begin(self, real, z=None, masks=None, z_g=None, label_smoothing=0.9):
         """d_compute_grads + the following G step's training forward on its own lane (pipelined
@@ -221,14 +238,18 @@ class Engine:
         z, z_g = _f32(z, self.device, "noise"), _f32(z_g, self.device, "noise")
         masks = self._masks(masks, b, 2)
         hp = self._hyper(0.0, 0.5, 0.999, label_smoothing=label_smoothing)
-        _lib.check(self.lib.siggan_step_begin(self._h, _ptr(real), b, _ptr(z), _ptr(masks), _ptr(z_g), C.byref(hp),
+        real_ptr = None if self._take_staged(real) else _ptr(real)      # NULL: the batch staged by stage_real
+        _lib.check(self.lib.siggan_step_begin(self._h, real_ptr, b, _ptr(z), _ptr(masks), _ptr(z_g), C.byref(hp),
                                               _ptr(self.metrics), self._stream()))
 
     def train_step(self, real, z_d=None, masks=None, z_g=None, lr_d=2e-4, lr_g=2e-4, beta1=0.5, beta2=0.999, eps=1e-8,
-                   label_smoothing=0.9, clip=None, sync=True):
-        """One pipelined G+D step (n_critic = 1): same results as d_step followed by g_step."""
+                   label_smoothing=0.9, clip=None, sync=True, next_real=None):
+        """One pipelined G+D step (n_critic = 1): same results as d_step followed by g_step.  next_real: the
+        following step's real batch, if the loop already has it (see stage_real)."""
         self.step_begin(real, z_d, masks, z_g, label_smoothing)
         dm = self.d_apply(lr_d, beta1, beta2, eps, clip, 1.0, sync)
+        if next_real is not None:
+            self.stage_real(next_real)
         self.g_compute_grads(real.shape[0])
         gm = self.g_apply(lr_g, beta1, beta2, eps, clip, 1.0, sync)
         if sync:

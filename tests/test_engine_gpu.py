@@ -246,3 +246,35 @@ def test_execution_modes_are_bitwise_identical():
             for a, b in zip(ref[0], state):
                 assert torch.equal(a, b), f"mode graph={graph} overlap={overlap} pipelined={pipelined} changed the result"
             assert mets == ref[1]
+
+
+def test_staged_next_batch_is_bitwise_identical():
+    """siggan_stage_real: D(real) of step t+1 runs beside the Generator backward of step t.  With the
+    library's own RNG (z and dropout drawn on the device) the staged sequence must reproduce the
+    un-staged one bit for bit -- parameters, Adam moments, BatchNorm statistics and every metric --
+    including when a staged batch is dropped (different tensor passed) or the weights are touched."""
+    from hipcommon import cuda, make_engine
+    size, latent, batch = 64, 100, 16
+    reals = [cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"] + 7 * t))) for t in range(5)]
+
+    def run(kind):
+        eng = make_engine(size, latent, batch, warm=True)
+        eng.seed(1234)
+        mets = []
+        for t in range(4):
+            nxt = reals[t + 1] if kind != "plain" else None
+            if kind == "dropped" and t == 1:
+                nxt = reals[4]                      # staged batch that the next step does not use
+            mets.append(eng.train_step(reals[t], clip=0.5, next_real=nxt))
+            if kind == "touched" and t == 2:
+                eng.params_changed()                # forces the D(real) forward started ahead of time to be redone
+        state = [x.clone() for x in (eng.g_params, eng.d_params, eng.g_exp_avg, eng.d_exp_avg_sq, eng.g_bn_mean, eng.g_bn_var)]
+        eng.close()
+        return state, mets
+
+    ref_state, ref_mets = run("plain")
+    for kind in ("staged", "dropped", "touched"):
+        state, mets = run(kind)
+        assert mets == ref_mets, kind
+        for a, b in zip(ref_state, state):
+            assert torch.equal(a, b), f"{kind}: staging the next batch changed the result"
