@@ -25,6 +25,9 @@ void launch_randn(float* out, int64_t n, const DevState* st, uint32_t stream_id,
 void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uint32_t stream_id, hipStream_t s,
                       int64_t elem0 = 0, uint32_t ctr_add = 0);
 // out = mask * (1/keep)
+// several tables in one launch (same element / counter conventions)
+void launch_dropnoise_multi(int nt, float* const* out, const int64_t* n, const int64_t* elem0, const uint32_t* sid, float keep,
+                            const DevState* st, hipStream_t s, uint32_t ctr_add = 0);
 void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, hipStream_t s);
 void launch_tick(DevState* st, hipStream_t s);
 
@@ -50,7 +53,9 @@ void launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s);
 // ---- Generator pieces ---------------------------------------------------------------------
 // y[n][f'] = z[n,:] . W[f,:] + b[f],  f' = hw*C0 + c  <->  f = c*16 + hw   (NHWC feature order)
 void launch_fc_pack(const float* W, float* Wt, int K, int C0, hipStream_t s);   // Wt[k][f'] = W[f][k]
-void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s);
+// bn_affine_relu != nullptr (eval): y = relu((z.Wt + b) * scale + shift) with [scale | shift] of the folded BatchNorm1d
+void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s,
+                   const float* bn_affine_relu = nullptr);
 // dW[f][k] = sum_n dy[n][f'] z[n][k];  db[f] = sum_n dy[n][f']
 void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s);
 
@@ -96,8 +101,9 @@ void launch_cls_features(const float* act, float* feat, int B, int C, hipStream_
 void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* probs, float* dlogit,
                 float* metrics, int is_g_step, hipStream_t s);
 // dv[n][hw][c] = dlogit[n] * wcp[hw*C+c] * leaky'(act) * noise[n][c]
-void launch_cls_bwd(const float* dlogit, const float* wcp, const float* act, const float* noise, float slope,
-                    float* dv, int B, int C, hipStream_t s);
+// from the logits (rows < n0: target y0, the rest y1; each segment's mean): d(logit) is recomputed with k_bce's expression
+void launch_cls_bwd(const float* logits, int n0, float y0, float y1, const float* wcp, const float* act, const float* noise,
+                    float slope, float* dv, int B, int C, hipStream_t s);
 // dWc (torch order c*16+hw) and dbc
 void launch_cls_wgrad(const float* dlogit, const float* act, float* dWc, float* dbc, int B, int C, hipStream_t s);
 // out[c] = sum_r x[r][c]

@@ -62,6 +62,25 @@ void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uin
     hipLaunchKernelGGL(k_dropnoise, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, out, n, keep, 1.0f / keep, st, sid, elem0 / 4,
                        ctr_add);
 }
+// all layers' tables in one launch: table t covers threads [pre[t], pre[t+1])
+struct NoiseTable { float* out[8]; int64_t n[8]; int64_t elem0[8]; uint32_t sid[8]; int64_t pre[9]; int nt; };
+__global__ void k_dropnoise_multi(const NoiseTable tb, float keep, float inv, const DevState* __restrict__ st, uint32_t ctr_add) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= tb.pre[tb.nt]) return;
+    int t = 0;
+    while (g >= tb.pre[t + 1]) ++t;
+    const int64_t q = g - tb.pre[t];
+    const uint4 r = draw(st, (uint64_t)(tb.elem0[t] / 4 + q), tb.sid[t], ctr_add);
+    const uint32_t x[4] = {r.x, r.y, r.z, r.w};
+    float* o = tb.out[t];
+    for (int j = 0; j < 4 && q * 4 + j < tb.n[t]; ++j) o[q * 4 + j] = u01(x[j]) < keep ? inv : 0.f;
+}
+void launch_dropnoise_multi(int nt, float* const* out, const int64_t* n, const int64_t* elem0, const uint32_t* sid, float keep,
+                            const DevState* st, hipStream_t s, uint32_t ctr_add) {
+    NoiseTable tb; tb.nt = nt; tb.pre[0] = 0;
+    for (int t = 0; t < nt; ++t) { tb.out[t] = out[t]; tb.n[t] = n[t]; tb.elem0[t] = elem0[t]; tb.sid[t] = sid[t]; tb.pre[t + 1] = tb.pre[t] + (n[t] + 3) / 4; }
+    hipLaunchKernelGGL(k_dropnoise_multi, dim3(cdiv(tb.pre[nt], 256)), dim3(256), 0, s, tb, keep, 1.0f / keep, st, ctr_add);
+}
 void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, hipStream_t s) {
     hipLaunchKernelGGL(k_mask_to_noise, dim3(cdiv(n, 256)), dim3(256), 0, s, mask, out, n, 1.0f / keep);
 }
@@ -383,7 +402,8 @@ void launch_fc_pack(const float* W, float* Wt, int K, int C0, hipStream_t s) {
 }
 // one thread = one feature f' x 8 batch rows; z rows broadcast from LDS; 20 weight loads in flight
 __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, const float* __restrict__ Wt,
-                                                const float* __restrict__ b, float* __restrict__ y, int B, int K, int C0) {
+                                                const float* __restrict__ b, float* __restrict__ y, int B, int K, int C0,
+                                                const float* __restrict__ bn) {
     extern __shared__ float sz[];   // [8][K]
     const int F = C0 * 16;
     const int fp = blockIdx.x * 256 + threadIdx.x, nb = blockIdx.y * 8;
@@ -413,12 +433,21 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, con
         for (int j = 0; j < 8; ++j) acc[j] = fmaf(sz[j * K + k], w, acc[j]);
     }
     const float bias = b[(fp % C0) * 16 + fp / C0];
+    if (bn) {            // eval mode: BatchNorm1d folded to scale/shift + ReLU, the pre-BN tensor is not kept
+        const float sc = bn[fp], sf = bn[F + fp];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (nb + j < B) y[(size_t)(nb + j) * F + fp] = fmaxf(fmaf(acc[j] + bias, sc, sf), 0.f);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         if (nb + j < B) y[(size_t)(nb + j) * F + fp] = acc[j] + bias;
 }
-void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s) {
-    hipLaunchKernelGGL(k_fc_fwd, dim3(cdiv(C0 * 16, 256), cdiv(B, 8)), dim3(256), 8 * K * sizeof(float), s, z, Wt, b, y, B, K, C0);
+void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s,
+                   const float* bn_affine_relu) {
+    hipLaunchKernelGGL(k_fc_fwd, dim3(cdiv(C0 * 16, 256), cdiv(B, 8)), dim3(256), 8 * K * sizeof(float), s, z, Wt, b, y, B, K, C0,
+                       bn_affine_relu);
 }
 // dW[f][k] = sum_n dy[n][f'] * z[n][k],  db[f] = sum_n dy[n][f'].  A thread owns feature f' and a group of
 // FK latent columns: every dy value it loads feeds FK FMAs (z rows broadcast from LDS, 64 batch rows per
@@ -989,6 +1018,7 @@ void launch_cls_features(const float* act, float* feat, int B, int C, hipStream_
     hipLaunchKernelGGL(k_cls_features, dim3(cdiv(total, 256)), dim3(256), 0, s, act, feat, total, C);
 }
 
+__device__ __forceinline__ float bce_dlogit(float x, float y, float inv_count);
 // nn.Sigmoid + nn.BCELoss(mean) per segment and its gradient w.r.t. the logit (torch formulas:
 // log clamped at -100; grad_p = (p - y) / max((1 - p) * p, 1e-12) / count; dlogit = grad_p * p * (1 - p))
 __global__ __launch_bounds__(256) void k_bce(const float* __restrict__ logits, int B, int n0, float y0, float y1,
@@ -1004,9 +1034,8 @@ __global__ __launch_bounds__(256) void k_bce(const float* __restrict__ logits, i
         const float y = s0 ? y0 : y1;
         const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);
         const float loss = -(y * lp + (1.0f - y) * lq);
-        const float gp = (p - y) / fmaxf((1.0f - p) * p, 1e-12f) * (s0 ? c0 : c1);
         if (probs) probs[n] = p;
-        if (dlogit) dlogit[n] = gp * ((1.0f - p) * p);
+        if (dlogit) dlogit[n] = bce_dlogit(x, y, s0 ? c0 : c1);
         if (s0) { l0 += loss; p0 += p; a0 += p > 0.5f ? 1.f : 0.f; }
         else    { l1 += loss; p1 += p; a1 += p < 0.5f ? 1.f : 0.f; }
     }
@@ -1027,21 +1056,32 @@ void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* p
     hipLaunchKernelGGL(k_bce, dim3(1), dim3(256), 0, s, logits, B, n0, y0, y1, probs, dlogit, metrics, is_g_step);
 }
 
-__global__ void k_cls_bwd(const float* __restrict__ dlogit, const float* __restrict__ wcp, const float* __restrict__ act,
-                          const float* __restrict__ noise, float slope, float* __restrict__ dv, int64_t total, int C) {
+// d(logit) of sigmoid + BCE(mean) for row n, k_bce's own expression (so both kernels agree bit for bit)
+__device__ __forceinline__ float bce_dlogit(float x, float y, float inv_count) {
+    const float p = 1.0f / (1.0f + expf(-x));
+    const float gp = (p - y) / fmaxf((1.0f - p) * p, 1e-12f) * inv_count;
+    return gp * ((1.0f - p) * p);
+}
+// d(classifier input) * leaky'(a) * dropout.  Takes the logits, not d(logit): the backward chain then does not
+// wait for k_bce (metrics + d(logit) for the classifier's weight gradient), which runs beside it.
+__global__ void k_cls_bwd(const float* __restrict__ logits, int B, int n0, float y0, float y1, const float* __restrict__ wcp,
+                          const float* __restrict__ act, const float* __restrict__ noise, float slope, float* __restrict__ dv,
+                          int64_t total, int C) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int F = 16 * C;
     const int j = (int)(i % F), c = j % C;
     const int64_t n = i / F;
-    float g = dlogit[n] * wcp[j] * (act[i] > 0.f ? 1.f : slope);
+    const bool s0 = n < n0;
+    const float dl = bce_dlogit(logits[n], s0 ? y0 : y1, 1.0f / (float)(s0 ? (n0 > 0 ? n0 : 1) : (B - n0 > 0 ? B - n0 : 1)));
+    float g = dl * wcp[j] * (act[i] > 0.f ? 1.f : slope);
     if (noise) g *= noise[n * C + c];
     dv[i] = g;
 }
-void launch_cls_bwd(const float* dlogit, const float* wcp, const float* act, const float* noise, float slope, float* dv,
-                    int B, int C, hipStream_t s) {
+void launch_cls_bwd(const float* logits, int n0, float y0, float y1, const float* wcp, const float* act, const float* noise,
+                    float slope, float* dv, int B, int C, hipStream_t s) {
     const int64_t total = (int64_t)B * 16 * C;
-    hipLaunchKernelGGL(k_cls_bwd, dim3(cdiv(total, 256)), dim3(256), 0, s, dlogit, wcp, act, noise, slope, dv, total, C);
+    hipLaunchKernelGGL(k_cls_bwd, dim3(cdiv(total, 256)), dim3(256), 0, s, logits, B, n0, y0, y1, wcp, act, noise, slope, dv, total, C);
 }
 __global__ void k_cls_wgrad(const float* __restrict__ dlogit, const float* __restrict__ act, float* __restrict__ dWc,
                             float* __restrict__ dbc, int B, int C) {

@@ -405,12 +405,15 @@ static GConvArgs gconv_args(siggan_ctx* c) {
 static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s,
                            float* partial = nullptr, float* slab_k = nullptr) {
     if (!partial) partial = c->partial;
-    launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s);
-    if (training)
+    if (!training) {     // eval: BatchNorm1d + ReLU folded into the fc epilogue
+        launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->g_a[0], B, c->latent, c->gC[0], s, c->g_bne[0]);
+    } else {
+        launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s);
         launch_bn_train_stats(c->fc_y, B, c->F, GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), c->st.g_bn_running_mean,
                               c->st.g_bn_running_var, c->st.g_bn_batches, c->g_bn[0], partial, c->gC[0], BN_MOMENTUM,
                               BN_EPS, s);
-    launch_bn_relu(c->fc_y, c->g_a[0], B, c->F, training ? c->g_bn[0] : c->g_bne[0], s);
+        launch_bn_relu(c->fc_y, c->g_a[0], B, c->F, c->g_bn[0], s);
+    }
     for (int l = 1; l <= c->Lg; ++l) {
         const int Hi = 4 << (l - 1), Ci = c->gC[l - 1], Co = c->gC[l];
         GConvArgs a = gconv_args(c);
@@ -460,15 +463,20 @@ static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool d
 // (D step); want_dimage: continue to d(pre-tanh image) (G step).  The chain of input-gradients
 // runs on lane m; each block's weight gradient (lane a) and bias gradient (lane b) only need that
 // block's d(pre-activation) and run beside the rest of the chain.
+struct BceSpec { int n0; float y0, y1; float* mt; int is_g; };   // rows < n0: target y0, the rest y1 (each segment's mean)
+
 static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, const float* x1, int Bd, bool dropout,
-                            bool want_wgrad, bool want_dimage) {
+                            bool want_wgrad, bool want_dimage, const BceSpec& bce) {
     const float slope = c->cfg.leaky_slope;
     const int Ld = c->Ld;
-    launch_cls_bwd(c->dlogit, c->wcp, c->d_a[Ld], dropout ? c->d_noise[Ld] : nullptr, slope, c->d_dv[Ld], Bd, c->dC[Ld], L.m);
-    if (want_wgrad) {
-        L.fork(L.b);
+    // sigmoid + BCE: losses / means into the metrics, d(logit) for the classifier's weight gradient -- on lane b; the
+    // chain below recomputes d(logit) from the logits and does not wait for it
+    L.fork(L.b);
+    launch_bce(c->logits, Bd, bce.n0, bce.y0, bce.y1, c->probs, c->dlogit, bce.mt, bce.is_g, L.b);
+    launch_cls_bwd(c->logits, bce.n0, bce.y0, bce.y1, c->wcp, c->d_a[Ld], dropout ? c->d_noise[Ld] : nullptr, slope, c->d_dv[Ld], Bd,
+                   c->dC[Ld], L.m);
+    if (want_wgrad)
         launch_cls_wgrad(c->dlogit, c->d_a[Ld], DG(c, di_cls_w(c)), DG(c, di_cls_b(c)), Bd, c->dC[Ld], L.b);
-    }
     for (int l = Ld; l >= 2; --l) {
         const int Ho = c->S >> l, Hi = 2 * Ho, Co = c->dC[l], Ci = c->dC[l - 1];
         if (want_wgrad) {
@@ -491,8 +499,9 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
     if (want_wgrad) {
         L.fork(L.b);
         launch_conv1_wgrad(c->d_dv[1], x0, n0, x1, DG(c, di_w(1)), DG(c, di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
-        L.join(L.a); L.join(L.b);
+        L.join(L.a);
     }
+    L.join(L.b);
     if (want_dimage)
         launch_conv1_dgrad_tanh(c->d_dv[1], DP(c, di_w(1)), x0, c->dpre, Bd, c->S, c->dC[1], L.m);
 }
@@ -537,15 +546,20 @@ static void make_noise(siggan_ctx* c, const float* masks, int B, int p0, int p1,
     const float keep = 1.0f - c->cfg.dropout;
     int64_t sumC = 0;
     for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l];
+    if (!masks) {
+        float* out[8]; int64_t n[8], e0[8]; uint32_t sid[8];
+        for (int l = 1; l <= c->Ld; ++l) {
+            const int64_t nl = (int64_t)B * c->dC[l];
+            out[l - 1] = c->d_noise[l] + p0 * nl; n[l - 1] = nl * (p1 - p0); e0[l - 1] = p0 * nl; sid[l - 1] = 16 + l;
+        }
+        launch_dropnoise_multi(c->Ld, out, n, e0, sid, keep, c->dev, s, ctr_add);
+        return;
+    }
     int64_t pre = 0;
     for (int l = 1; l <= c->Ld; ++l) {
         const int64_t n = (int64_t)B * c->dC[l];
-        if (masks) {
-            for (int p = p0; p < p1; ++p)
-                launch_mask_to_noise(masks + (int64_t)p * B * sumC + (int64_t)B * pre, c->d_noise[l] + p * n, n, keep, s);
-        } else {
-            launch_dropnoise(c->d_noise[l] + p0 * n, n * (p1 - p0), keep, c->dev, 16 + l, s, p0 * n, ctr_add);
-        }
+        for (int p = p0; p < p1; ++p)
+            launch_mask_to_noise(masks + (int64_t)p * B * sumC + (int64_t)B * pre, c->d_noise[l] + p * n, n, keep, s);
         pre += c->dC[l];
     }
 }
@@ -582,14 +596,13 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     if (k.spec_g) { e_spec = L.next(); (void)hipEventRecord(e_spec, L.m); }
     d_forward_rows(c, c->img, B, B, drop, L.m, c->slab_k);           // D(fake) into rows [B, 2B)
     if (k.pre_real == 2) (void)hipStreamWaitEvent(L.m, c->ev_dreal, 0);
-    launch_bce(c->logits, 2 * B, B, k.ls, 0.f, c->probs, c->dlogit, k.mt, 0, L.m);
     if (k.spec_g) {
         (void)hipStreamWaitEvent(c->s_c, e_spec, 0);
         if (!k.has_zg) launch_randn(c->z_g, (int64_t)B * c->latent, c->dev, 2, c->s_c);
         g_forward_pass(c, c->z_g, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2);
         (void)hipEventRecord(c->ev_gfwd, c->s_c);
     }
-    d_backward_pass(c, L, c->real_stage, B, c->img, 2 * B, drop, true, false);
+    d_backward_pass(c, L, c->real_stage, B, c->img, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0});
 }
 
 static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
@@ -608,8 +621,7 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         zg = c->z; img = c->img;
     }
     d_forward_rows(c, img, 0, B, false, L.m, c->slab_k);             // D.eval(): dropout off (train...py:350)
-    launch_bce(c->logits, B, B, 1.0f, 1.0f, c->probs, c->dlogit, k.mt, 1, L.m);
-    d_backward_pass(c, L, img, B, img, B, false, false, true);       // through D into the image; no D weight grads
+    d_backward_pass(c, L, img, B, img, B, false, false, true, BceSpec{B, 1.0f, 1.0f, k.mt, 1});   // through D into the image; no D weight grads
     if (k.pre_real) {
         // siggan_stage_real: the NEXT D step's D(real) forward needs the Discriminator as it is now (its
         // update is behind us) and the activation rows this step is done with: run it on lane c beside the
