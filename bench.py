@@ -160,12 +160,17 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        threads = min(16, os.cpu_count() or 1)                  # this job's CPU share on the GPU box
-        v, n = cpu_baseline(threads)
-        v8, n8 = cpu_baseline(min(8, threads), budget_s=8.0)
+        # two thread counts (this job's CPU share on the GPU box is 16; torch's oneDNN convs do not always scale past
+        # 8): the faster one is the baseline, the other is quoted in `sample`
+        runs = []
+        for threads in sorted({min(16, os.cpu_count() or 1), min(8, os.cpu_count() or 1)}, reverse=True):
+            v, n = cpu_baseline(threads, budget_s=10.0)
+            runs.append((v, threads, n))
+        (v, threads, n), rest = max(runs), [r for r in runs if r != max(runs)]
+        other = "; ".join(f"{round(r[0], 1)} images/s with {r[1]} threads ({r[2]} steps)" for r in rest)
         cpu = {"value": round(v, 1), "unit": "images/s", "cores": threads, "kind": "port",
                "sample": f"{n} G+D steps of the same workload (batch {BATCH}, 64x64, fp32) by oracle/siggan_oracle.py "
-                         f"on torch CPU with {threads} threads; {round(v8, 1)} images/s with {min(8, threads)} threads ({n8} steps)"}
+                         f"on torch CPU with {threads} threads" + (f"; {other}" if other else "")}
 
     if rank == 0:
         imgs = BATCH * world * args.steps
