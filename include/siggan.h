@@ -203,6 +203,22 @@ int siggan_op_adam(siggan_ctx *ctx, float *p_dev, float *g_dev, float *m_dev, fl
                    int64_t n, int32_t step, const siggan_hyper *hp, void *stream);
 /* library RNG: n standard normals / n Bernoulli(keep) keep-masks */
 int siggan_op_randn(siggan_ctx *ctx, float *out_dev, int64_t n, void *stream);
+/* Input pipeline (replaces SignatureDataset.__getitem__ + the transform chain of
+ * get_train_transforms / get_val_transforms, data_loader_signatures.py:107-138,153-243, for a whole batch):
+ * out[b] = Normalize(ToTensor(hflip?(RandomAffine_scale(RandomRotation(cache[index[b]])))))  as (batch,1,size,size)
+ * fp32 in HBM, from an (N,size,size) uint8 cache of decoded + resized images resident in HBM.  Needs no context.
+ *   params_dev [batch][8] int32: {mode, a0, a1, a2, a3, a4, a5, flags} -- rotation stage: mode 0 = copy, 1 = Pillow's
+ *     16.16 fixed-point affine (output (x,y) samples input ((a2 + y*a1 + x*a0) >> 16, (a5 + y*a4 + x*a3) >> 16)),
+ *     2 = per-axis tables (rows 0,1 of tables_dev); flags bit 0: horizontal flip, bit 1: scale stage present
+ *   tables_dev [batch][4][size] int16: source column / row per output column / row (-1 = outside -> fill); rows 2,3 are
+ *     the scale stage (Pillow's ImagingScaleAffine positions, tabulated by the host in double precision)
+ *   lut_dev [256] fp32: value of each byte after ToTensor + Normalize;  augment = 0: out[b] = lut[cache[index[b]]].
+ * The host side (signature-gan_amd/data_loader_signatures.py) draws indices, angles and scales with the reference
+ * DataLoader's own RNG protocol and fills params / tables. */
+int siggan_augment_batch(int32_t device, const uint8_t *cache_dev, int64_t n_images, const int32_t *index_dev,
+                         const int32_t *params_dev, const int16_t *tables_dev, const float *lut_dev,
+                         float *out_dev, int32_t batch, int32_t size, int32_t augment, int32_t fill,
+                         void *stream);
 /* measurement hook (bench.py roofline leg): while enabled, every MFMA implicit-GEMM launch is
  * bracketed by HIP events on the stream it is launched on.  siggan_prof_read synchronises the
  * device and returns, for kernel slot idx (0..siggan_prof_slots()-1): its name, launch count,

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "siggan_op_conv4x4s2_wgrad": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "siggan_op_adam": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, C.POINTER(Hyper), _P]),
     "siggan_op_randn": (C.c_int, [_P, _P, _I64, _P]),
+    "siggan_augment_batch": (C.c_int, [_I32, _P, _I64, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "siggan_prof_enable": (C.c_int, [_P, _I32]),
     "siggan_prof_slots": (_I32, []),
     "siggan_prof_read": (C.c_int, [_P, _I32, C.c_char_p, _I32, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -118,4 +118,8 @@ void launch_adam_prepare(DevState* st, float* steps, int ntensors, double lr, do
 void launch_adam(float* p, float* g, float* m, float* v, int64_t n, const DevState* st, double beta1,
                  double beta2, double eps, int write_back_grad, hipStream_t s);
 
+// input pipeline: out[b] = lut[ resample(cache[index[b]]) ], (B,1,S,S) fp32 from an (N,S,S) uint8 cache (see k_augment)
+void launch_augment(const uint8_t* cache, int64_t n_images, const int32_t* index, const int32_t* prm, const int16_t* tabs,
+                    const float* lut, float* out, int B, int S, int augment, int fill, hipStream_t s);
+
 }  // namespace siggan

@@ -1102,6 +1102,58 @@ void launch_cls_wgrad(const float* dlogit, const float* act, float* dWc, float* 
 }
 
 // =========================================================================================
+// input pipeline: per-sample nearest-neighbour rotation + scale of cached 8-bit images (byte work, HBM-bound)
+// =========================================================================================
+// One thread per output pixel.  The two resampling stages of the reference's transform chain
+// (RandomRotation, then RandomAffine(scale), data_loader_signatures.py:176-193, both Pillow nearest-neighbour
+// transforms with fill) are composed backwards: the scale stage's per-axis source tables (Pillow's
+// ImagingScaleAffine, running double sums -- tabulated on the host) give the pixel of the rotated image, the
+// rotation's 16.16 fixed-point map (Pillow's affine_fixed) gives the pixel of the cached image.  ToTensor +
+// Normalize is a 256-entry table computed by torch itself.
+//   prm[b] = {mode, a0, a1, a2, a3, a4, a5, flags}: mode 0 copy, 1 fixed point, 2 per-axis tables (tab rows 0, 1);
+//   flags bit 0 horizontal flip (last), bit 1 scale stage present (tab rows 2, 3).  Table value -1: outside.
+__global__ __launch_bounds__(256) void k_augment(const uint8_t* __restrict__ cache, const int32_t* __restrict__ index,
+                                                 const int32_t* __restrict__ prm, const int16_t* __restrict__ tabs,
+                                                 const float* __restrict__ lut, float* __restrict__ out, int S, int augment,
+                                                 int fill, int64_t n_images) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= S * S) return;
+    const int y = p / S, x = p - y * S;
+    int64_t img = index[b];
+    img = img < 0 ? 0 : (img >= n_images ? n_images - 1 : img);      // never read outside the cache
+    const uint8_t* src = cache + (size_t)img * S * S;
+    int v = fill;
+    if (!augment) {
+        v = src[p];
+    } else {
+        const int32_t* q = prm + b * 8;
+        const int16_t* t = tabs + (size_t)b * 4 * S;
+        const int flags = q[7];
+        int xs = (flags & 1) ? S - 1 - x : x, ys = y;
+        bool ok = true;
+        if (flags & 2) { xs = t[2 * S + xs]; ys = t[3 * S + ys]; ok = xs >= 0 && ys >= 0; }
+        if (ok) {
+            const int mode = q[0];
+            if (mode == 0) {
+                v = src[ys * S + xs];
+            } else if (mode == 1) {
+                const int xin = (q[3] + ys * q[2] + xs * q[1]) >> 16, yin = (q[6] + ys * q[5] + xs * q[4]) >> 16;
+                if (xin >= 0 && xin < S && yin >= 0 && yin < S) v = src[yin * S + xin];
+            } else {
+                const int xin = t[xs], yin = t[S + ys];
+                if (xin >= 0 && yin >= 0) v = src[yin * S + xin];
+            }
+        }
+    }
+    out[(size_t)b * S * S + p] = lut[v & 255];
+}
+void launch_augment(const uint8_t* cache, int64_t n_images, const int32_t* index, const int32_t* prm, const int16_t* tabs,
+                    const float* lut, float* out, int B, int S, int augment, int fill, hipStream_t s) {
+    hipLaunchKernelGGL(k_augment, dim3(cdiv((int64_t)S * S, 256), B), dim3(256), 0, s, cache, index, prm, tabs, lut, out, S,
+                       augment, fill, n_images);
+}
+
+// =========================================================================================
 // clip + Adam
 // =========================================================================================
 __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {

@@ -1006,6 +1006,19 @@ extern "C" int siggan_debug_tensor(siggan_ctx* c, const char* name, int32_t idx,
     return SIGGAN_OK;
 }
 
+extern "C" int siggan_augment_batch(int32_t device, const uint8_t* cache_dev, int64_t n_images, const int32_t* index_dev,
+                                    const int32_t* params_dev, const int16_t* tables_dev, const float* lut_dev, float* out_dev,
+                                    int32_t batch, int32_t size, int32_t augment, int32_t fill, void* stream) {
+    if (!cache_dev || !index_dev || !lut_dev || !out_dev) return fail(SIGGAN_E_INVALID, "null tensor");
+    if (augment && (!params_dev || !tables_dev)) return fail(SIGGAN_E_INVALID, "augment needs params and tables");
+    if (batch < 1 || n_images < 1 || size < 1 || size > 1024) return fail(SIGGAN_E_INVALID, "bad batch / cache / image size");
+    if (fill < 0 || fill > 255) return fail(SIGGAN_E_INVALID, "fill must be a byte value");
+    HIPCHK(hipSetDevice(device));
+    launch_augment(cache_dev, n_images, index_dev, params_dev, tables_dev, lut_dev, out_dev, batch, size, augment != 0, fill, (hipStream_t)stream);
+    LAUNCHCHK();
+    return SIGGAN_OK;
+}
+
 extern "C" int siggan_op_randn(siggan_ctx* c, float* out_dev, int64_t n, void* stream) {
     if (!c || !out_dev || n < 1) return fail(SIGGAN_E_INVALID, "bad argument");
     HIPCHK(hipSetDevice(c->cfg.device));

@@ -8,9 +8,9 @@ reference's UI parses (``[Trainer] ...``, the tqdm postfix ``D=, G=, D(r)=, D(f)
 ``[Epoch NNNN] G_loss: ... | D_loss: ... | D(real): ... | D(fake): ...``), the
 ``epoch_%04d.png`` sample grids, CSV/JSON logs and the cooperative ``--stop_file``.
 
-Data: the reference's own ``data_loader_signatures.create_data_loader`` is used when it is
-importable (it needs torchvision); otherwise a plain PIL folder loader without augmentation
-(the decode/augment pipeline is outside the accelerated path).
+Data: ``data_loader_signatures.create_data_loader`` of this package -- images decoded once
+into an HBM-resident uint8 cache, the reference's augmentation chain applied per batch by one kernel,
+sample order and random draws those of the reference's DataLoader.
 """
 import argparse
 import csv
@@ -154,36 +154,11 @@ def save_sample_grid(images: torch.Tensor, path, nrow: int = 8, padding: int = 2
     Image.fromarray(arr, mode="L").save(str(path))
 
 
-def _folder_loader(data_dir: str, batch_size: int, image_size: int):
-    """Fallback loader: grayscale, resize, map to [-1, 1], shuffle, full batches only."""
-    from PIL import Image
-    exts = {".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff"}
-    files = sorted(p for p in Path(data_dir).rglob("*") if p.suffix.lower() in exts)
-    if not files:
-        raise FileNotFoundError(f"no images under {data_dir}")
-    import numpy as np
-    data = torch.empty(len(files), 1, image_size, image_size)
-    for i, p in enumerate(files):
-        im = Image.open(p).convert("L").resize((image_size, image_size), Image.BILINEAR)
-        data[i, 0] = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0 - 0.5) / 0.5
-
-    class _Loader:
-        def __len__(self):
-            return len(files) // batch_size
-
-        def __iter__(self):
-            perm = torch.randperm(len(files))
-            for b in range(len(self)):
-                yield data[perm[b * batch_size:(b + 1) * batch_size]]
-    return _Loader()
-
-
 def create_data_loader(data_dir: str, batch_size: int, num_workers: int, image_size: int, **kw):
-    try:
-        from data_loader_signatures import create_data_loader as ref_loader   # the reference's own module
-        return ref_loader(data_dir=data_dir, batch_size=batch_size, num_workers=num_workers, image_size=image_size, **kw)
-    except ImportError:
-        return _folder_loader(data_dir, batch_size, image_size)
+    """The device input pipeline (data_loader_signatures.py of this package): decoded images cached in HBM, the
+    reference's augmentation chain as one kernel per batch, its DataLoader's sample order and random draws."""
+    from .data_loader_signatures import create_data_loader as device_loader
+    return device_loader(data_dir=data_dir, batch_size=batch_size, num_workers=num_workers, image_size=image_size, **kw)
 
 
 class GANTrainer:
@@ -283,7 +258,8 @@ class GANTrainer:
         if data_loader is None:
             print(f"[Trainer] Loading data from: {cfg.data_dir}")
             data_loader = create_data_loader(data_dir=cfg.data_dir, batch_size=cfg.batch_size, num_workers=cfg.num_workers,
-                                             image_size=cfg.image_size, shuffle=True, augment=True, drop_last=True)
+                                             image_size=cfg.image_size, shuffle=True, augment=True, drop_last=True,
+                                             device=str(self.model.device))
         self.data_loader = data_loader
         print(f"[Trainer] Data loaded: {len(data_loader)} batches per epoch")
         if self.start_epoch == 0:
