@@ -84,11 +84,19 @@ def main():
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # SIGGAN_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks then
+        # share devices round-robin; RCCL itself refuses two ranks on one GPU).  The driver's runs use nccl = RCCL.
+        backend = os.environ.get("SIGGAN_DIST_BACKEND", "nccl")
+        local = local % torch.cuda.device_count() if backend != "nccl" else local
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+        local = 0
+    dev = torch.device("cuda", local)
 
     eng = Engine(latent_dim=LATENT, image_size=SIZE, max_batch=BATCH, device=str(dev), seed=2 + rank)
     eng.init_reference(seed=0)                                  # identical initial weights on every rank
