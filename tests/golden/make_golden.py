@@ -287,8 +287,13 @@ if __name__ == "__main__":
     if "--manifest-only" in sys.argv:
         checkpoint_manifests()
         sys.exit(0)
+    if "--case" in sys.argv:                      # one more fixture: --case SIZE LATENT BATCH
+        k = sys.argv.index("--case")
+        make(int(sys.argv[k + 1]), int(sys.argv[k + 2]), int(sys.argv[k + 3]), full_image=False)
+        sys.exit(0)
     make(64, 100, 4, full_image=True)
     make(64, 100, 64, full_image=False)
     make(128, 128, 4, full_image=False)
     make(128, 128, 32, full_image=False)
+    make(64, 100, 128, full_image=False)          # BASELINE configs[3]: conv G/D 64x64, batch 128
     checkpoint_manifests()
