@@ -55,45 +55,7 @@ def test_forward_vs_oracle_and_golden(size, latent, batch):
     eng.close()
 
 
-def _nchw(t):
-    return t.permute(0, 3, 1, 2).contiguous().cpu()
-
-
-def hip_signs_d(eng, size, batch, passes):
-    """Sign decisions (activation > 0) the HIP path took in the Discriminator, per pass and
-    block, NCHW bool -- handed to the oracle's backward (oracle._ActWithGivenSign)."""
-    out = []
-    for p in range(passes):
-        for l, c in enumerate(d_chans(size), start=1):
-            h = size >> l
-            a = eng.debug_tensor("d_a", l, (passes * batch, h, h, c))[p * batch:(p + 1) * batch]
-            out.append(_nchw(a) > 0)
-    return out
-
-
-def hip_signs_g(eng, size, batch):
-    chain = O.G_CHAIN[size]
-    out = []
-    for l, c in enumerate(chain):
-        h = 4 << l
-        a = _nchw(eng.debug_tensor("g_a", l, (batch, h, h, c)))
-        out.append((a > 0).reshape(batch, -1) if l == 0 else a > 0)
-    return out
-
-
-def count_sign_flips(signs, recorded, keep=None):
-    """Disagreements between the HIP sign decisions and the oracle's own; every one must be a
-    pre-activation within rounding of zero (|x| <= 1e-5 of the layer's scale)."""
-    n = 0
-    for i, (s, x) in enumerate(zip(signs, recorded)):
-        bad = s.reshape(x.shape) != (x > 0)
-        if keep is not None and keep[i] is not None:
-            bad &= keep[i][:, :, None, None] > 0          # dropped planes carry no gradient
-        if bad.any():
-            assert float(x[bad].abs().max()) <= 1e-5 * float(x.abs().max()), "sign disagreement away from zero"
-            n += int(bad.sum())
-    assert n <= 16, f"{n} borderline sign decisions differ"
-    return n
+from hipcommon import count_sign_flips, hip_signs_d, hip_signs_g  # noqa: E402  (sign decisions of the HIP path, shared with smoke())
 
 
 def _check_step(eng, which, f, tag, met, o_met, o_grads, o_sd, o_opt, strict_golden, init_sd, init_opt, fresh, lr=2e-4):
