@@ -44,6 +44,8 @@ struct WgradArgs {
     const float* L;       // [B][2Hs][2Ws][Cl] (large spatial)
     float* slab;          // [nsplit][Cs][16*Cl]
     float* dw;            // result, torch layout: dw[(i*Cl + l)*16 + tap]
+    float* db;            // optional: db[i] = sum_pix S[pix][i] (the bias gradient when S is d(pre-activation)); partials
+                          // live behind the weight slabs, slab[nsplit*Cs*16*Cl + z*Cs + i]
     int B, Cs, Cl;
     int lgHs, lgWs, lgCl;
     int K;                // B*Hs*Ws pixels
@@ -66,7 +68,7 @@ extern Prof* g_prof;
 
 void launch_gconv(const GConvArgs& a, hipStream_t st);
 // fills a.dw (through the slabs + k_wgrad_reduce when K is split); returns the number of K splits
-// (slab must hold max_splits*Cs*16*Cl floats)
+// (slab must hold max_splits*Cs*(16*Cl + 1) floats)
 int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st);
 // torch layout (O,I,4,4) -> down pack [O][tap*I + i];  torch (I,O,4,4) -> up pack [4][O][t*I + i]
 void launch_pack_down(const float* w, float* wp, int O, int I, hipStream_t st);

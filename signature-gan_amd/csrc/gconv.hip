@@ -408,8 +408,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
         if (nk > 1) WG_LOAD_TILE(1)
     }
     __syncthreads();
+    const bool bias_lane = a.db != nullptr && j0 == 0 && tid < BM;     // column sums of S ride along in the first column tile
+    float bsum = 0.f;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+        if (bias_lane) {
+            const float* col = sA + buf * BK * LDA + tid;
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) bsum += col[k * LDA];
+        }
         const float* pA = sA + buf * BK * LDA + lh * LDA + wm * (32 * TM) + li;
         const float* pB = sB + buf * BK * LDB + lh * LDB + wn * (32 * TN) + li;
         float fa[2][TM], fb[2][TN];
@@ -440,6 +447,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
 
 #undef WG_LOAD_TILE
 #undef WG_STORE_TILE
+    if (bias_lane) {
+        if (gridDim.z == 1) a.db[i0 + tid] = bsum;
+        else a.slab[(size_t)gridDim.z * a.Cs * N + (size_t)blockIdx.z * a.Cs + i0 + tid] = bsum;
+    }
     if (gridDim.z == 1 && a.dw) {
         // a single split: un-permute straight into the torch layout, column j = tap*Cl + l -> dw[(row*Cl + l)*16 + tap]
 #pragma unroll
@@ -467,7 +478,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
         }
 }
 
-static void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int Cs, int Cl, hipStream_t st);
+static void launch_wgrad_reduce(const float* slab, float* dw, float* db, int nsplit, int Cs, int Cl, hipStream_t st);
 
 int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
     // 64x64 tiles (one 32x32 accumulator per wave keeps the fp32 MFMA pipe full): many tiles,
@@ -494,29 +505,38 @@ int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
     } else {
         hipLaunchKernelGGL((k_wgrad<64, 64, 2, 2>), grid, dim3(256), 0, st, a);
     }
-    if (nsplit > 1) launch_wgrad_reduce(a.slab, a.dw, nsplit, a.Cs, 1 << a.lgCl, st);
+    if (nsplit > 1) launch_wgrad_reduce(a.slab, a.dw, a.db, nsplit, a.Cs, 1 << a.lgCl, st);
     return nsplit;
 }
 
 // dw[(s*Cl + l)*16 + tap] = sum_z slab[z][s][tap*Cl + l].  A block owns 64 consecutive slab columns;
 // SL lanes per column each add every SL-th slab, then LDS combines the lanes in lane order (the sum
 // order is fixed by (nsplit, SL) alone: bitwise reproducible).
-__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
-                                                       int Cs, int lgCl) {
+__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, float* __restrict__ db,
+                                                       int nsplit, int Cs, int lgCl) {
     __shared__ float sh[16][64];
     const int N = 16 << lgCl, Cl = 1 << lgCl;
     const size_t total = (size_t)Cs * N;
     const int cl = threadIdx.x & 63, zl = threadIdx.x >> 6, SL = blockDim.x >> 6;
-    const size_t idx = (size_t)blockIdx.x * 64 + cl;
+    const size_t wblocks = total / 64;
+    const bool bias = blockIdx.x >= wblocks;                       // the blocks behind the weight columns: db
+    const size_t idx = bias ? (size_t)(blockIdx.x - wblocks) * 64 + cl : (size_t)blockIdx.x * 64 + cl;
+    const float* src = bias ? slab + (size_t)nsplit * total : slab;
+    const size_t zstride = bias ? (size_t)Cs : total;
+    const bool live = !bias || idx < (size_t)Cs;
     float acc = 0.f;
+    if (live) {
 #pragma unroll 4
-    for (int z = zl; z < nsplit; z += SL) acc += slab[(size_t)z * total + idx];
+        for (int z = zl; z < nsplit; z += SL) acc += src[(size_t)z * zstride + idx];
+    }
     if (SL > 1) {
         sh[zl][cl] = acc;
         __syncthreads();
         if (zl != 0) return;
         for (int k = 1; k < SL; ++k) acc += sh[k][cl];
     }
+    if (!live) return;
+    if (bias) { db[idx] = acc; return; }
     const int j = (int)(idx % N), s_ = (int)(idx / N);
     const int tap = j >> lgCl, l = j & (Cl - 1);
     dw[((size_t)s_ * Cl + l) * 16 + tap] = acc;
@@ -524,11 +544,12 @@ __global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-static void launch_wgrad_reduce(const float* slab, float* dw, int nsplit, int Cs, int Cl, hipStream_t st) {
+static void launch_wgrad_reduce(const float* slab, float* dw, float* db, int nsplit, int Cs, int Cl, hipStream_t st) {
     const size_t total = (size_t)Cs * 16 * Cl;                 // a multiple of 64 (Cs, Cl >= 32)
     int SL = 1;
     while (SL < 16 && SL < nsplit) SL *= 2;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(total / 64)), dim3(64 * SL), 0, st, slab, dw, nsplit, Cs, ilog2(Cl));
+    const unsigned blocks = (unsigned)(total / 64) + (db ? (unsigned)((Cs + 63) / 64) : 0u);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(64 * SL), 0, st, slab, dw, db, nsplit, Cs, ilog2(Cl));
 }
 
 // ------------------------------------------------------------------------------------------

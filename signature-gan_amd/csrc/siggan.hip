@@ -480,13 +480,13 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
     for (int l = Ld; l >= 2; --l) {
         const int Ho = c->S >> l, Hi = 2 * Ho, Co = c->dC[l], Ci = c->dC[l - 1];
         if (want_wgrad) {
-            L.fork(L.a); L.fork(L.b);                      // d_dv[l] is complete on m here
+            L.fork(L.a);                                   // d_dv[l] is complete on m here
             WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
             w.S = c->d_dv[l]; w.L = c->d_a[l - 1]; w.slab = c->slab; w.dw = DG(c, di_w(l)); w.B = Bd; w.Cs = Co; w.Cl = Ci;
             w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
-            const int max_splits = (int)(c->slab_floats / ((int64_t)Co * 16 * Ci));
+            w.db = DG(c, di_b(l));                           // bias gradient = column sums of d(pre-activation): rides in the same kernel
+            const int max_splits = (int)(c->slab_floats / ((int64_t)Co * (16 * Ci + 1)));
             launch_wgrad(w, max_splits, L.a);
-            launch_colsum(c->d_dv[l], (int64_t)Bd * Ho * Ho, Co, DG(c, di_b(l)), c->partial_b, L.b);
         }
         // input gradient ("up" form): contract Cout, produce Cin at (Hi x Hi); fused leaky'/dropout of block l-1
         GConvArgs a = gconv_args(c);
@@ -525,7 +525,7 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
         WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
         w.S = c->g_a[l - 1]; w.L = c->g_da[l]; w.slab = c->slab; w.dw = GG(c, gi_up_w(l)); w.B = B; w.Cs = Ci; w.Cl = Co;
         w.lgHs = ilog2i(Hi); w.lgWs = w.lgHs; w.lgCl = ilog2i(Co); w.K = B * Hi * Hi;
-        const int max_splits = (int)(c->slab_floats / ((int64_t)Ci * 16 * Co));
+        const int max_splits = (int)(c->slab_floats / ((int64_t)Ci * (16 * Co + 1)));
         launch_wgrad(w, max_splits, L.a);
         // input gradient ("down" form): out = Cin at Hi, contract Cout over 16 taps
         GConvArgs a = gconv_args(c);
@@ -928,7 +928,7 @@ extern "C" int siggan_op_conv4x4s2_wgrad(siggan_ctx* c, const float* small_dev, 
     WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
     w.S = small_dev; w.L = large_dev; w.slab = c->slab; w.dw = dw_dev; w.B = batch; w.Cs = c_small; w.Cl = c_large;
     w.lgHs = w.lgWs = ilog2i(h_small); w.lgCl = ilog2i(c_large); w.K = batch * h_small * h_small;
-    const int max_splits = (int)(c->slab_floats / ((int64_t)c_small * 16 * c_large));
+    const int max_splits = (int)(c->slab_floats / ((int64_t)c_small * (16 * c_large + 1)));
     launch_wgrad(w, max_splits, s);
     LAUNCHCHK();
     return SIGGAN_OK;
