@@ -408,14 +408,18 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
         if (nk > 1) WG_LOAD_TILE(1)
     }
     __syncthreads();
-    const bool bias_lane = a.db != nullptr && j0 == 0 && tid < BM;     // column sums of S ride along in the first column tile
+    // column sums of S (the bias gradient when S is d(pre-activation)) ride along in the first column tile: thread t
+    // owns column t % BM and the k rows [kq * KQ, kq * KQ + KQ) of every K-tile, the slices are added at the end
+    constexpr int NQ = 256 / BM, KQ = BK / NQ;
+    const bool bias_blk = a.db != nullptr && j0 == 0;
+    const int bcol = tid % BM, kq = tid / BM;
     float bsum = 0.f;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (bias_lane) {
-            const float* col = sA + buf * BK * LDA + tid;
-#pragma unroll 8
-            for (int k = 0; k < BK; ++k) bsum += col[k * LDA];
+        if (bias_blk) {
+            const float* col = sA + buf * BK * LDA + kq * KQ * LDA + bcol;
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) bsum += col[k * LDA];
         }
         const float* pA = sA + buf * BK * LDA + lh * LDA + wm * (32 * TM) + li;
         const float* pB = sB + buf * BK * LDB + lh * LDB + wn * (32 * TN) + li;
@@ -447,9 +451,16 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
 
 #undef WG_LOAD_TILE
 #undef WG_STORE_TILE
-    if (bias_lane) {
-        if (gridDim.z == 1) a.db[i0 + tid] = bsum;
-        else a.slab[(size_t)gridDim.z * a.Cs * N + (size_t)blockIdx.z * a.Cs + i0 + tid] = bsum;
+    if (bias_blk) {                                   // the main loop's last barrier has passed: LDS is free
+        smem[kq * BM + bcol] = bsum;
+        __syncthreads();
+        if (tid < BM) {
+            float t = smem[tid];
+#pragma unroll
+            for (int q = 1; q < NQ; ++q) t += smem[q * BM + tid];
+            if (gridDim.z == 1) a.db[i0 + tid] = t;
+            else a.slab[(size_t)gridDim.z * a.Cs * N + (size_t)blockIdx.z * a.Cs + i0 + tid] = t;
+        }
     }
     if (gridDim.z == 1 && a.dw) {
         // a single split: un-permute straight into the torch layout, column j = tap*Cl + l -> dw[(row*Cl + l)*16 + tap]
