@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SIGGAN_ABI_VERSION 1
+#define SIGGAN_ABI_VERSION 2   /* 2: siggan_stage_real, siggan_augment_batch */
 
 enum {
     SIGGAN_OK = 0,

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be loaded before the library; see module docst
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsiggan_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 M_COUNT = 16
 METRIC_INDEX = {"d_loss": 0, "d_loss_real": 1, "d_loss_fake": 2, "d_real_mean": 3, "d_fake_mean": 4,
                 "d_real_acc": 5, "d_fake_acc": 6, "d_grad_norm": 7, "g_loss": 8, "g_fake_mean": 9,
