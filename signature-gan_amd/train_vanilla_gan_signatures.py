@@ -277,13 +277,8 @@ class GANTrainer:
                     break
                 sums, seen = [0.0, 0.0, 0.0, 0.0], 0
                 bar = tqdm(data_loader, desc=f"Epoch {epoch + 1}/{cfg.epochs}", leave=True, ncols=120) if tqdm else data_loader
-                for real_batch in bar:
-                    if isinstance(real_batch, (list, tuple)):
-                        real_batch = real_batch[0]
-                    for _ in range(cfg.n_critic):
-                        dm = self._train_discriminator(real_batch)
-                    gm = self._train_generator(real_batch.size(0))
-                    self.global_step += 1
+                def account(dm, gm):
+                    nonlocal seen
                     seen += 1
                     for i, v in enumerate((dm["d_loss"], gm["g_loss"], dm["d_real_mean"], dm["d_fake_mean"])):
                         sums[i] += v
@@ -291,10 +286,37 @@ class GANTrainer:
                     if tqdm:
                         bar.set_postfix({"D": f"{dm['d_loss']:.4f}", "G": f"{gm['g_loss']:.4f}",
                                          "D(r)": f"{dm['d_real_mean']:.3f}", "D(f)": f"{dm['d_fake_mean']:.3f}"})
+
+                it = iter(bar)
+                nxt = next(it, None)
+                pending = None                                    # metrics of the step still running on the device
+                while nxt is not None:
+                    real_batch, nxt = nxt, next(it, None)         # one batch of look-ahead: the next D(real) runs early
+                    if isinstance(real_batch, (list, tuple)):
+                        real_batch = real_batch[0]
+                    if cfg.n_critic == 1:
+                        # both steps as one pipelined engine step (same results as the two calls below); its metrics are
+                        # read one step late, so the host prepares the next step while this one runs
+                        ahead = nxt[0] if isinstance(nxt, (list, tuple)) else nxt
+                        now = self.model.train_step(real_batch, next_real=ahead if ahead is not None and ahead.shape == real_batch.shape else None,
+                                                    clip=cfg.gradient_clip_value, deferred=True)
+                        if pending is not None:
+                            m = pending.get()
+                            account(m, m)
+                        pending = now
+                    else:
+                        for _ in range(cfg.n_critic):
+                            dm = self._train_discriminator(real_batch)
+                        gm = self._train_generator(real_batch.size(0))
+                        account(dm, gm)
+                    self.global_step += 1
                     if self._stop_requested():
                         print("\n[Trainer] Stop requested. Stopping after current batch...")
                         stopped = True
                         break
+                if pending is not None:
+                    m = pending.get()
+                    account(m, m)
                 if seen == 0:
                     print("[Trainer] No batches processed for this epoch. Stopping.")
                     break

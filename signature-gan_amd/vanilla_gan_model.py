@@ -18,6 +18,31 @@ from .engine import Engine
 from .generator_vanilla_gan import Generator
 
 
+class _PendingMetrics:
+    """Metrics of a step that is still running: an asynchronous copy into pinned host memory + an event."""
+
+    def __init__(self, model, engine, with_norms: bool):
+        self.model, self.with_norms = model, with_norms
+        self.keys = engine.D_KEYS + engine.G_KEYS
+        self.host = torch.empty(engine.metrics.numel(), dtype=torch.float32, pin_memory=True)
+        self.host.copy_(engine.metrics, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.value = None
+
+    def get(self) -> Dict[str, float]:
+        if self.value is None:
+            from ._lib import METRIC_INDEX
+            self.event.synchronize()
+            out = {k: float(self.host[METRIC_INDEX[k]]) for k in self.keys}
+            if self.with_norms:         # the trainer's variant reports the pre-clip norms (train...py:330-337, 370-376)
+                for k in ("d_grad_norm", "g_grad_norm"):
+                    out[k] = float(self.host[METRIC_INDEX[k]])
+            self.model.d_losses.append(out["d_loss"]); self.model.g_losses.append(out["g_loss"])
+            self.value = out
+        return self.value
+
+
 class VanillaGAN(nn.Module):
     def __init__(self, latent_dim: int = 100, image_size: int = 64, image_channels: int = 1, g_lr: float = 2e-4,
                  d_lr: float = 2e-4, beta1: float = 0.5, beta2: float = 0.999, label_smoothing: float = 0.9,
@@ -85,16 +110,21 @@ class VanillaGAN(nn.Module):
         self.g_losses.append(m["g_loss"])
         return m
 
-    def train_step(self, real_images: torch.Tensor, n_critic: int = 1) -> Dict[str, float]:
+    def train_step(self, real_images: torch.Tensor, n_critic: int = 1, next_real: Optional[torch.Tensor] = None,
+                   clip: Optional[float] = None, deferred: bool = False):
         """vanilla_gan_model.py:308-336.  With n_critic == 1 the two steps run as ONE pipelined engine
-        step (the G step's forward beside the D step's backward; bit-identical results)."""
+        step (the G step's forward beside the D step's backward; bit-identical results) with a single
+        metrics read-back.  Extras: next_real -- the following step's batch, if the loop already holds it (its
+        D(real) forward then runs beside this step's Generator backward); clip -- the trainer's
+        gradient_clip_value (train_vanilla_gan_signatures.py:262-279); deferred -- return a handle whose
+        .get() yields the metric dict, so the caller can enqueue the next step before it waits for this one."""
         if n_critic != 1:
             metrics: Dict[str, float] = {}
             for i in range(n_critic):
-                d = self.train_discriminator_step(real_images)
+                d = self.train_discriminator_step(real_images, clip=clip)
                 if i == n_critic - 1:
                     metrics.update(d)
-            metrics.update(self.train_generator_step(real_images.size(0)))
+            metrics.update(self.train_generator_step(real_images.size(0), clip=clip))
             return metrics
         self.discriminator.train()
         self.generator.train()          # the mode the reference leaves G in after train_generator_step
@@ -103,16 +133,16 @@ class VanillaGAN(nn.Module):
         real = real_images.to(self._device, torch.float32)
         e = self.engine
         e.step_begin(real, None, None, None, self.label_smoothing)
-        m = e.d_apply(hd["lr"], hd["beta1"], hd["beta2"], hd["eps"], None, 1.0, sync=False) or {}
+        e.d_apply(hd["lr"], hd["beta1"], hd["beta2"], hd["eps"], clip, 1.0, sync=False)
+        if next_real is not None:
+            e.stage_real(next_real.to(self._device, torch.float32))
         e.g_compute_grads(real.shape[0])
-        m = e.g_apply(hg["lr"], hg["beta1"], hg["beta2"], hg["eps"], None, 1.0, sync=True)
-        host = e.metrics.cpu()
-        from ._lib import METRIC_INDEX
-        out = {k: float(host[METRIC_INDEX[k]]) for k in e.D_KEYS + e.G_KEYS}
-        self.d_losses.append(out["d_loss"]); self.g_losses.append(out["g_loss"])
+        e.g_apply(hg["lr"], hg["beta1"], hg["beta2"], hg["eps"], clip, 1.0, sync=False)
         self.global_step += 1
         self.discriminator.eval()       # reference: train_generator_step ends with D in eval mode
-        return out
+        pending = _PendingMetrics(self, e, bool(clip))
+        return pending if deferred else pending.get()
+
 
     # ---- generation (vanilla_gan_model.py:338-407) ---------------------------------------------------
     @torch.no_grad()
