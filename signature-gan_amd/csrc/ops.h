@@ -20,14 +20,11 @@ struct DevState {
 
 // ---- RNG (Philox4x32-10, counter = (index, stream, call counter)) --------------------------
 void launch_randn(float* out, int64_t n, const DevState* st, uint32_t stream_id, hipStream_t s);
-// out = u < keep ? 1/keep : 0
-// elements [elem0, elem0 + n) of the stream's table (elem0 % 4 == 0), drawn at counter rng_ctr + ctr_add
-void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uint32_t stream_id, hipStream_t s,
-                      int64_t elem0 = 0, uint32_t ctr_add = 0);
-// out = mask * (1/keep)
-// several tables in one launch (same element / counter conventions)
+// dropout multiplier tables (0 or 1/keep) of several blocks in one launch: table t = elements [elem0[t], elem0[t] + n[t])
+// (elem0 % 4 == 0) of stream sid[t], drawn at counter rng_ctr + ctr_add
 void launch_dropnoise_multi(int nt, float* const* out, const int64_t* n, const int64_t* elem0, const uint32_t* sid, float keep,
                             const DevState* st, hipStream_t s, uint32_t ctr_add = 0);
+// out = mask * (1/keep)
 void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, hipStream_t s);
 void launch_tick(DevState* st, hipStream_t s);
 
@@ -59,11 +56,6 @@ void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, in
 // dW[f][k] = sum_n dy[n][f'] z[n][k];  db[f] = sum_n dy[n][f']
 void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s);
 
-// BatchNorm.  perm_c0 > 0: channel c' of the data maps to torch index (c' % perm_c0)*16 + c'/perm_c0
-// (BatchNorm1d behind the fc); 0: identity.  Per-layer scratch `bn` holds 6*C floats:
-// [scale | shift | mean | rstd | c1 | c2].
-void launch_bn_eval_affine(const float* gamma, const float* beta, const float* rmean, const float* rvar,
-                           float* bn, int C, int perm_c0, float eps, hipStream_t s);
 // training statistics over R rows + running-stat update (momentum, unbiased var) + batches++
 void launch_bn_train_stats(const float* y, int64_t R, int C, const float* gamma, const float* beta,
                            float* rmean, float* rvar, int64_t* batches, float* bn, float* partial,
@@ -93,8 +85,6 @@ void launch_conv1_wgrad(const float* dv, const float* x0, int n0, const float* x
 // d(image) = conv1 input-gradient, times tanh' = 1 - img^2  ->  dpre
 void launch_conv1_dgrad_tanh(const float* dv, const float* W, const float* img, float* dpre, int B, int S,
                              int C, hipStream_t s);
-// classifier: logits[n] = act[n,:] . wcp + bc   (act NHWC-flattened, wcp the permuted weight)
-void launch_cls_pack(const float* Wc, float* wcp, int C, hipStream_t s);
 void launch_cls_fwd(const float* act, const float* wcp, const float* bc, float* logits, int B, int F, hipStream_t s);
 void launch_cls_features(const float* act, float* feat, int B, int C, hipStream_t s);
 // sigmoid + BCE (mean per segment) + d(logit); seg0 = first n0 rows with target y0, rest target y1
@@ -106,8 +96,6 @@ void launch_cls_bwd(const float* logits, int n0, float y0, float y1, const float
                     float slope, float* dv, int B, int C, hipStream_t s);
 // dWc (torch order c*16+hw) and dbc
 void launch_cls_wgrad(const float* dlogit, const float* act, float* dWc, float* dbc, int B, int C, hipStream_t s);
-// out[c] = sum_r x[r][c]
-void launch_colsum(const float* x, int64_t R, int C, float* out, float* partial, hipStream_t s);
 
 // ---- optimiser ------------------------------------------------------------------------------
 // reads steps[0], writes steps[i] += 1 for every tensor, derives the Adam scalars; with

@@ -40,14 +40,6 @@ __global__ void k_randn(float* __restrict__ out, int64_t n, const DevState* __re
     const float v[4] = {r0 * cosf(a0), r0 * sinf(a0), r1 * cosf(a1), r1 * sinf(a1)};
     for (int j = 0; j < 4 && t * 4 + j < n; ++j) out[t * 4 + j] = v[j];
 }
-__global__ void k_dropnoise(float* __restrict__ out, int64_t n, float keep, float inv, const DevState* __restrict__ st,
-                            uint32_t sid, int64_t t0, uint32_t ctr_add) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t * 4 >= n) return;
-    const uint4 r = draw(st, (uint64_t)(t0 + t), sid, ctr_add);
-    const uint32_t x[4] = {r.x, r.y, r.z, r.w};
-    for (int j = 0; j < 4 && t * 4 + j < n; ++j) out[t * 4 + j] = u01(x[j]) < keep ? inv : 0.f;
-}
 __global__ void k_mask_to_noise(const float* __restrict__ m, float* __restrict__ out, int64_t n, float inv) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = m[i] * inv;
@@ -56,11 +48,6 @@ __global__ void k_tick(DevState* st) { st->rng_ctr += 1; }
 
 void launch_randn(float* out, int64_t n, const DevState* st, uint32_t sid, hipStream_t s) {
     hipLaunchKernelGGL(k_randn, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, out, n, st, sid);
-}
-void launch_dropnoise(float* out, int64_t n, float keep, const DevState* st, uint32_t sid, hipStream_t s, int64_t elem0,
-                      uint32_t ctr_add) {
-    hipLaunchKernelGGL(k_dropnoise, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, out, n, keep, 1.0f / keep, st, sid, elem0 / 4,
-                       ctr_add);
 }
 // all layers' tables in one launch: table t covers threads [pre[t], pre[t+1])
 struct NoiseTable { float* out[8]; int64_t n[8]; int64_t elem0[8]; uint32_t sid[8]; int64_t pre[9]; int nt; };
@@ -229,10 +216,6 @@ __device__ __forceinline__ void gather2(const float* __restrict__ p0, const floa
     for (int k = 0; k < nl; ++k) { s += s0[k * W + cl]; q += s1[k * W + cl]; }
 }
 
-struct FSum {
-    const float4* x;
-    __device__ void operator()(int64_t r, int c4, int C4, float4& s0, float4& s1) const { add4(s0, x[r * C4 + c4]); }
-};
 struct FStats {   // shifted sums around the first row: robust single-pass variance
     const float4* y;
     __device__ void operator()(int64_t r, int c4, int C4, float4& s0, float4& s1) const {
@@ -256,38 +239,9 @@ struct FBnBwd {   // relu mask re-derived from y (a > 0 <=> fma(y, scale, shift)
 };
 
 
-__global__ __launch_bounds__(1024) void k_colsum_fin(const float* __restrict__ p0, int nch, int C, float* __restrict__ out) {
-    __shared__ float sh[2][16][64];
-    float s, q;
-    gather2(p0, nullptr, nch, C, s, q, sh);
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    if (threadIdx.x < 64 && c < C) out[c] = s;
-}
-void launch_colsum(const float* x, int64_t R, int C, float* out, float* partial, hipStream_t s) {
-    const ColPlan pl = col_plan(R, C);
-    float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
-    hipLaunchKernelGGL((k_colreduce<FSum>), dim3(pl.cbx, pl.nch), dim3(256), 0, s, FSum{(const float4*)x}, R, C, pl.cg, pl.rows, p0, p1);
-    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, pl.nch, C, out);
-}
-
 // =========================================================================================
 // BatchNorm
 // =========================================================================================
-__global__ void k_bn_eval_affine(const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 const float* __restrict__ rmean, const float* __restrict__ rvar,
-                                 float* __restrict__ bn, int C, int perm_c0, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const int t = perm16(c, perm_c0);
-    const float rstd = 1.0f / sqrtf(rvar[t] + eps);
-    const float sc = gamma[t] * rstd;
-    bn[c] = sc; bn[C + c] = beta[t] - rmean[t] * sc; bn[2 * C + c] = rmean[t]; bn[3 * C + c] = rstd;
-}
-void launch_bn_eval_affine(const float* gamma, const float* beta, const float* rmean, const float* rvar, float* bn,
-                           int C, int perm_c0, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(k_bn_eval_affine, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, rmean, rvar, bn, C, perm_c0, eps);
-}
-
 template <int W>
 __global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
                                const float* __restrict__ y, const float* __restrict__ gamma,
@@ -389,17 +343,7 @@ void launch_bn_bwd(float* da, const float* y, int64_t R, int C, float* bn, float
 // =========================================================================================
 // Generator fc (latent x weight) -- K = latent_dim is tiny; one thread per output
 // =========================================================================================
-// Wt[k][f'] = W[f][k]: k-major copy in the NHWC feature order, so lanes walk f' (coalesced)
-__global__ void k_fc_pack(const float* __restrict__ W, float* __restrict__ Wt, int K, int C0) {
-    const int F = C0 * 16;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)K * F) return;
-    const int fp = (int)(idx % F), k = (int)(idx / F);
-    Wt[idx] = W[(size_t)((fp % C0) * 16 + fp / C0) * K + k];
-}
-void launch_fc_pack(const float* W, float* Wt, int K, int C0, hipStream_t s) {
-    hipLaunchKernelGGL(k_fc_pack, dim3(cdiv((int64_t)K * C0 * 16, 256)), dim3(256), 0, s, W, Wt, K, C0);
-}
+// (Wt[k][f'] = W[f][k] is the k-major copy k_prepare keeps in the NHWC feature order, so lanes walk f' coalesced)
 // one thread = one feature f' x 8 batch rows; z rows broadcast from LDS; 20 weight loads in flight
 __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, const float* __restrict__ Wt,
                                                 const float* __restrict__ b, float* __restrict__ y, int B, int K, int C0,
@@ -972,14 +916,6 @@ void launch_conv1_dgrad_tanh(const float* dv, const float* W, const float* img, 
 // =========================================================================================
 // classifier, BCE
 // =========================================================================================
-__global__ void k_cls_pack(const float* __restrict__ Wc, float* __restrict__ wcp, int C) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;   // j = hw*C + c
-    if (j >= 16 * C) return;
-    wcp[j] = Wc[(j % C) * 16 + j / C];
-}
-void launch_cls_pack(const float* Wc, float* wcp, int C, hipStream_t s) {
-    hipLaunchKernelGGL(k_cls_pack, dim3(cdiv(16 * C, 256)), dim3(256), 0, s, Wc, wcp, C);
-}
 __device__ __forceinline__ float block_sum(float v, float* sh) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     const int w = threadIdx.x >> 6;
