@@ -351,9 +351,33 @@ __global__ __launch_bounds__(256) void k_gconv_up4(const GConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: the 2x2 output pixels of every input pixel ---------------------------------------------
+    // ---- epilogue: the workgroup's output -- the 2x2 output pixels of 128 consecutive input pixels of one image -- is one
+    // contiguous 64 KB range of the NHWC tensor (the row grid is a multiple of 128 pixels): assemble it in LDS in memory
+    // order, then store it with 16-byte lanes
     const int co = n0 + li;
     const float sc = a.epi == EPI_AFFINE_RELU ? a.scale[co] : 1.f, sf = a.epi == EPI_AFFINE_RELU ? a.shift[co] : 0.f;
+    const int Wo = 2 * Wr;
+    if (tiles_n == 1) {
+        float* const so = smem;                          // 128 * 4 * 32 floats; the main loop's last barrier has passed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int rl = ml >> a.lgWr, rw = ml & (Wr - 1);
+#pragma unroll
+            for (int cls = 0; cls < 4; ++cls) {
+                float v = acc[cls][r];
+                if (a.epi == EPI_AFFINE_RELU) v = fmaxf(fmaf(v, sc, sf), 0.f);
+                so[(((2 * rl + (cls >> 1)) * Wo) + 2 * rw + (cls & 1)) * BN + li] = v;
+            }
+        }
+        __syncthreads();
+        const int n = m0 >> (a.lgHr + a.lgWr), rh0 = (m0 >> a.lgWr) & (Hr - 1);
+        f32x4* const dst = reinterpret_cast<f32x4*>(a.out + ((size_t)n * a.Ho + 2 * rh0) * a.Wo * a.Co);
+        const f32x4* const src = reinterpret_cast<const f32x4*>(so);
+#pragma unroll
+        for (int q = 0; q < (BM * 4 * BN / 4) / 256; ++q) dst[q * 256 + tid] = src[q * 256 + tid];
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -411,7 +435,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int 
 Prof* g_prof = nullptr;
 const char* Prof::name(int id) {
     static const char* n[NID] = {"k_gconv<128,128>", "k_gconv<128,64>", "k_gconv<64,64>", "k_gconv<128,32>",
-                                 "k_wgrad<64,64>", "k_wgrad<64,128>", "k_wgrad<32,128>", "?"};
+                                 "k_wgrad<64,64>", "k_gconv_up4", "k_wgrad<32,128>", "?"};
     return n[id < 0 || id >= NID ? NID - 1 : id];
 }
 // The two events of a record are handed to hipExtLaunchKernelGGL, which stamps them with the
@@ -477,11 +501,11 @@ void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         return launch_cfg<64, 64, 2, 2>(a, st, 2, ns);
     }
     if (a.form == 1 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU) && a.Ci % BK == 0 && !getenv("SIGGAN_NO_UP4") &&
-        ((a.M + 127) / 128) * (a.Co / 32) >= 384) {
+        ((a.M + 127) / 128) * (a.Co / 32) >= 384 && a.M % 128 == 0 && ((1 << (a.lgHr + a.lgWr)) % 128) == 0) {
         // all four parity classes per workgroup (k_gconv_up4): the short-K Generator blocks
         dim3 grid(((a.M + 127) / 128) * (a.Co / 32));
         if (g_prof) {
-            g_prof->begin(3, 2.0 * a.M * a.Co * (double)(4 * a.Ci) * 4, st);
+            g_prof->begin(5, 2.0 * a.M * a.Co * (double)(4 * a.Ci) * 4, st);
             hipExtLaunchKernelGGL(k_gconv_up4, grid, dim3(256), 0, st, g_prof->recs.back().e0, g_prof->recs.back().e1, 0, a);
         } else {
             hipLaunchKernelGGL(k_gconv_up4, grid, dim3(256), 0, st, a);
