@@ -232,78 +232,70 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
 // (Generator blocks 3-4: K = 4 taps x 32-64 channels per class, i.e. 4-8 K-tiles -- the per-class kernel above spends
 // most of its time in prologue and epilogue there).  The four classes of an input pixel read a 3x3 neighbourhood
 // between them, each a 2x2 corner of it: input offset (oh, ow) in {-1,0,1}^2 feeds the classes with
-// ph in P(oh), pw in P(ow), P(-1) = {0}, P(0) = {0,1}, P(1) = {1}, through tap th = ph - oh, tw = pw - ow.  One
-// workgroup = 128 input pixels x 32 channels x 4 classes: 9 A-tiles per channel chunk instead of 16, a quarter of the
-// workgroups with four times the MFMA work each (four accumulators per wave), and the 2x2 output pixels of an input
-// pixel are written together.
+// ph in P(oh), pw in P(ow), P(-1) = {0}, P(0) = {0,1}, P(1) = {1}, through tap th = ph - oh, tw = pw - ow.
+// One workgroup = 128 consecutive input pixels of one image x 32 channels x 4 classes.  Its whole input -- the pixel
+// rows it covers plus a one-pixel halo, all CI channels -- is brought into LDS ONCE (one burst of independent loads,
+// zero outside the image); the nine taps are then shifted views of that patch, so the K loop stages only the small
+// weight tiles.  Four accumulators per wave; the 2x2 output pixels of the 128 input pixels form one contiguous 64 KB
+// range of the NHWC output, assembled in LDS and stored with 16-byte lanes.
 // ------------------------------------------------------------------------------------------
+template <int CI>
 __global__ __launch_bounds__(256) void k_gconv_up4(const GConvArgs a) {
-    constexpr int BM = 128, BN = 32, LD = BK + 4;
-    __shared__ __attribute__((aligned(16))) float smem[2 * LD * (BM + 4 * BN)];
-    float* const sA = smem;                          // [2][BM][LD]
-    float* const sB = smem + 2 * LD * BM;            // [2][4 classes][BN][LD]
+    constexpr int BM = 128, BN = 32, LD = BK + 4, LP = CI + 4, NCC = CI / BK;
+    constexpr int PATCH_PIX = 264;                   // (128 / Wr + 2) * (Wr + 2) for Wr = 16, 32, 64: 180, 204, 264
+    constexpr int SMEM = (PATCH_PIX * LP + 2 * 4 * BN * LD) > (BM * 4 * BN) ? (PATCH_PIX * LP + 2 * 4 * BN * LD) : (BM * 4 * BN);
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* const sP = smem;                          // [patch pixel][LP]
+    float* const sB = smem + PATCH_PIX * LP;         // [2][4 classes][BN][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int tiles_n = a.Co / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
-    const int Hr = 1 << a.lgHr, Wr = 1 << a.lgWr;
-    const int Ktot = 4 * a.Ci;
-    const int ncc = a.Ci / BK;                       // channel chunks per tap
-    const int nk = 9 * ncc;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const int Hr = 1 << a.lgHr, Wr = 1 << a.lgWr, Wp = Wr + 2;
+    const int Ktot = 4 * CI;
+    const int n_img = m0 >> (a.lgHr + a.lgWr), rh0 = (m0 >> a.lgWr) & (Hr - 1), rows = BM >> a.lgWr;
 
-    const int kc = tid & 7, rloc = tid >> 3;
-    const float* a_base[4];
-    int a_rh[4], a_rw[4];
+    // ---- the input patch: rows rh0-1 .. rh0+rows, columns -1 .. Wr, every channel ----------------------------
+    {
+        const float* const img = a.in + (size_t)n_img * a.Hi * a.Wi * CI;
+        const int nchunk = (rows + 2) * Wp * (CI / 4);
+        constexpr int NI = (PATCH_PIX * (CI / 4) + 255) / 256;      // loads per thread, all issued before the first LDS write
+        f32x4 v[NI];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int m = m0 + rloc + 32 * p;
-        if (m < a.M) {
-            const int n = m >> (a.lgHr + a.lgWr);
-            a_rh[p] = (m >> a.lgWr) & (Hr - 1); a_rw[p] = m & (Wr - 1);
-            a_base[p] = a.in + (size_t)n * a.Hi * a.Wi * a.Ci + kc * 4;
-        } else {
-            a_base[p] = a.in; a_rh[p] = -(1 << 20); a_rw[p] = -(1 << 20);
+        for (int q = 0; q < NI; ++q) {
+            const int i = tid + 256 * q;
+            const int pix = i / (CI / 4), ch = i - pix * (CI / 4);
+            const int pr = pix / Wp, pc = pix - pr * Wp;
+            const int ih = rh0 - 1 + pr, iw = pc - 1;
+            const bool ok = i < nchunk && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+            const float* src = ok ? img + ((size_t)ih * a.Wi + iw) * CI + ch * 4 : a.zeros;
+            v[q] = *reinterpret_cast<const f32x4*>(src);
+        }
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int i = tid + 256 * q;
+            if (i < nchunk) {
+                const int pix = i / (CI / 4), ch = i - pix * (CI / 4);
+                *reinterpret_cast<f32x4*>(sP + pix * LP + ch * 4) = v[q];
+            }
         }
     }
-    // B rows this thread stages: output channel n0 + rloc (rloc < 32), one 16-byte chunk per class slot
-    const float* const w_row = a.wp + (size_t)(n0 + rloc) * Ktot + kc * 4;
-
-    f32x4 ra[4], rb[4];
-    int l_k = 0;                                     // K-tile the next load_tile() fetches: (oh, ow, cc) = (l_k / (3 ncc) - 1, ...)
+    // ---- weight tiles: K-tile kt = (class, channel chunk); its four taps' [32 co][32 ci] tiles are staged together by
+    // thread (rloc = output channel, kc = 16-byte chunk), one tile ahead of the MFMAs ----------------------------------
+    const int kc = tid & 7, rloc = tid >> 3;
+    const float* const w_row = a.wp + (size_t)rloc * Ktot + kc * 4;
+    f32x4 rb[4];
+    int l_k = 0;
     auto load_tile = [&]() __attribute__((always_inline)) {
-        const int t9 = l_k / ncc, cc = l_k - t9 * ncc;
-        const int oh = t9 / 3 - 1, ow = t9 % 3 - 1;
+        const int cls = l_k / NCC, cc = l_k - cls * NCC;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int ih = a_rh[p] + oh, iw = a_rw[p] + ow;
-            const bool ok = (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
-            const float* src = ok ? a_base[p] + ((size_t)(ih * a.Wi + iw) * a.Ci + cc * BK) : a.zeros;
-            ra[p] = *reinterpret_cast<const f32x4*>(src);
-        }
-        if (rloc < BN) {
-#pragma unroll
-            for (int cls = 0; cls < 4; ++cls) {
-                const int ph = cls >> 1, pw = cls & 1, th = ph - oh, tw = pw - ow;
-                if ((unsigned)th < 2u && (unsigned)tw < 2u)
-                    rb[cls] = *reinterpret_cast<const f32x4*>(w_row + (size_t)cls * a.Co * Ktot + (th * 2 + tw) * a.Ci + cc * BK);
-            }
-        }
+        for (int t = 0; t < 4; ++t)
+            rb[t] = *reinterpret_cast<const f32x4*>(w_row + (size_t)cls * a.Co * Ktot + t * CI + cc * BK);
         ++l_k;
     };
-    auto store_tile = [&](int buf, int kt) __attribute__((always_inline)) {
-        const int t9 = kt / ncc, oh = t9 / 3 - 1, ow = t9 % 3 - 1;
-        float* dA = sA + buf * LD * BM + rloc * LD + kc * 4;
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(dA + 32 * p * LD) = ra[p];
-        if (rloc < BN) {
-#pragma unroll
-            for (int cls = 0; cls < 4; ++cls) {
-                const int th = (cls >> 1) - oh, tw = (cls & 1) - ow;
-                if ((unsigned)th < 2u && (unsigned)tw < 2u)
-                    *reinterpret_cast<f32x4*>(sB + ((buf * 4 + cls) * BN + rloc) * LD + kc * 4) = rb[cls];
-            }
-        }
+        for (int t = 0; t < 4; ++t)
+            *reinterpret_cast<f32x4*>(sB + ((buf * 4 + t) * BN + rloc) * LD + kc * 4) = rb[t];
     };
 
     f32x16 acc[4];
@@ -313,84 +305,73 @@ __global__ __launch_bounds__(256) void k_gconv_up4(const GConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[cls][r] = 0.f;
 
     load_tile();
-    store_tile(0, 0);
-    if (nk > 1) load_tile();
+    store_tile(0);
+    load_tile();
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const int t9 = kt / ncc, oh = t9 / 3 - 1, ow = t9 % 3 - 1;
-        const float* pA = sA + buf * LD * BM + (wave * 32 + li) * LD + 4 * lh;
-        const float* pB = sB + (buf * 4 * BN + li) * LD + 4 * lh;
-        bool use[4];
+    // this lane's pixel (A-operand row) inside the patch
+    const int ml = wave * 32 + li;
+    const float* const pP = sP + (((ml >> a.lgWr) + 1) * Wp + (ml & (Wr - 1)) + 1) * LP + 4 * lh;
+
 #pragma unroll
-        for (int cls = 0; cls < 4; ++cls) use[cls] = (unsigned)((cls >> 1) - oh) < 2u && (unsigned)((cls & 1) - ow) < 2u;
-        f32x4 fa[2], fb[2][4];
-        fa[0] = *reinterpret_cast<const f32x4*>(pA);
+    for (int cls = 0; cls < 4; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+        for (int cc = 0; cc < NCC; ++cc) {
+            const int kt = cls * NCC + cc, buf = kt & 1;
+            // tap t = (th, tw) reads the patch at input offset (ph - th, pw - tw)
+            const float* pA[4];
 #pragma unroll
-        for (int cls = 0; cls < 4; ++cls)
-            if (use[cls]) fb[0][cls] = *reinterpret_cast<const f32x4*>(pB + cls * BN * LD);
+            for (int t = 0; t < 4; ++t) pA[t] = pP + ((ph - (t >> 1)) * Wp + (pw - (t & 1))) * LP + cc * BK;
+            const float* pB = sB + (buf * 4 * BN + li) * LD + 4 * lh;
+            f32x4 fa[2][4], fb[2][4];
 #pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
-            const int cur = c & 1, nxt = cur ^ 1;
-            if (c + 1 < BK / 8) {
-                fa[nxt] = *reinterpret_cast<const f32x4*>(pA + 8 * (c + 1));
-#pragma unroll
-                for (int cls = 0; cls < 4; ++cls)
-                    if (use[cls]) fb[nxt][cls] = *reinterpret_cast<const f32x4*>(pB + cls * BN * LD + 8 * (c + 1));
+            for (int t = 0; t < 4; ++t) {
+                fa[0][t] = *reinterpret_cast<const f32x4*>(pA[t]);
+                fb[0][t] = *reinterpret_cast<const f32x4*>(pB + t * BN * LD);
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int c = 0; c < BK / 8; ++c) {
+                const int cur = c & 1, nxt = cur ^ 1;
+                if (c + 1 < BK / 8) {
 #pragma unroll
-                for (int cls = 0; cls < 4; ++cls)
-                    if (use[cls]) acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][t], fb[cur][cls][t], acc[cls], 0, 0, 0);
-            if (c == 0 && kt + 1 < nk) store_tile(buf ^ 1, kt + 1);
-            if (c == 1 && kt + 2 < nk) load_tile();
+                    for (int t = 0; t < 4; ++t) {
+                        fa[nxt][t] = *reinterpret_cast<const f32x4*>(pA[t] + 8 * (c + 1));
+                        fb[nxt][t] = *reinterpret_cast<const f32x4*>(pB + t * BN * LD + 8 * (c + 1));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][t][u], fb[cur][t][u], acc[cls], 0, 0, 0);
+                if (c == 0 && kt + 1 < 4 * NCC) store_tile(buf ^ 1);
+                if (c == 1 && kt + 2 < 4 * NCC) load_tile();
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
-    // ---- epilogue: the workgroup's output -- the 2x2 output pixels of 128 consecutive input pixels of one image -- is one
-    // contiguous 64 KB range of the NHWC tensor (the row grid is a multiple of 128 pixels): assemble it in LDS in memory
-    // order, then store it with 16-byte lanes
-    const int co = n0 + li;
-    const float sc = a.epi == EPI_AFFINE_RELU ? a.scale[co] : 1.f, sf = a.epi == EPI_AFFINE_RELU ? a.shift[co] : 0.f;
+    // ---- epilogue: assemble the contiguous output range in LDS in memory order, store with 16-byte lanes ---------
+    const float sc = a.epi == EPI_AFFINE_RELU ? a.scale[li] : 1.f, sf = a.epi == EPI_AFFINE_RELU ? a.shift[li] : 0.f;
     const int Wo = 2 * Wr;
-    if (tiles_n == 1) {
-        float* const so = smem;                          // 128 * 4 * 32 floats; the main loop's last barrier has passed
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ml = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int rl = ml >> a.lgWr, rw = ml & (Wr - 1);
-#pragma unroll
-            for (int cls = 0; cls < 4; ++cls) {
-                float v = acc[cls][r];
-                if (a.epi == EPI_AFFINE_RELU) v = fmaxf(fmaf(v, sc, sf), 0.f);
-                so[(((2 * rl + (cls >> 1)) * Wo) + 2 * rw + (cls & 1)) * BN + li] = v;
-            }
-        }
-        __syncthreads();
-        const int n = m0 >> (a.lgHr + a.lgWr), rh0 = (m0 >> a.lgWr) & (Hr - 1);
-        f32x4* const dst = reinterpret_cast<f32x4*>(a.out + ((size_t)n * a.Ho + 2 * rh0) * a.Wo * a.Co);
-        const f32x4* const src = reinterpret_cast<const f32x4*>(so);
-#pragma unroll
-        for (int q = 0; q < (BM * 4 * BN / 4) / 256; ++q) dst[q * 256 + tid] = src[q * 256 + tid];
-        return;
-    }
+    float* const so = smem;                              // 128 * 4 * 32 floats; the main loop's last barrier has passed
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= a.M) continue;
-        const int n = m >> (a.lgHr + a.lgWr), rh = (m >> a.lgWr) & (Hr - 1), rw = m & (Wr - 1);
+        const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int rl = mr >> a.lgWr, rw = mr & (Wr - 1);
 #pragma unroll
         for (int cls = 0; cls < 4; ++cls) {
-            const size_t opix = ((size_t)n * a.Ho + 2 * rh + (cls >> 1)) * a.Wo + 2 * rw + (cls & 1);
             float v = acc[cls][r];
             if (a.epi == EPI_AFFINE_RELU) v = fmaxf(fmaf(v, sc, sf), 0.f);
-            a.out[opix * a.Co + co] = v;
+            so[(((2 * rl + (cls >> 1)) * Wo) + 2 * rw + (cls & 1)) * BN + li] = v;
         }
     }
+    __syncthreads();
+    f32x4* const dst = reinterpret_cast<f32x4*>(a.out + ((size_t)n_img * a.Ho + 2 * rh0) * a.Wo * BN);
+    const f32x4* const src = reinterpret_cast<const f32x4*>(so);
+#pragma unroll
+    for (int q = 0; q < (BM * 4 * BN / 4) / 256; ++q) dst[q * 256 + tid] = src[q * 256 + tid];
 }
 
 // split-K tail: out = epilogue(sum_z slab[z]) over the NHWC output (4 channels per thread)
@@ -500,16 +481,15 @@ void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         const int ns = splits(blocks(64, 64));
         return launch_cfg<64, 64, 2, 2>(a, st, 2, ns);
     }
-    if (a.form == 1 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU) && a.Ci % BK == 0 && !getenv("SIGGAN_NO_UP4") &&
-        ((a.M + 127) / 128) * (a.Co / 32) >= 384 && a.M % 128 == 0 && ((1 << (a.lgHr + a.lgWr)) % 128) == 0) {
-        // all four parity classes per workgroup (k_gconv_up4): the short-K Generator blocks
-        dim3 grid(((a.M + 127) / 128) * (a.Co / 32));
-        if (g_prof) {
-            g_prof->begin(5, 2.0 * a.M * a.Co * (double)(4 * a.Ci) * 4, st);
-            hipExtLaunchKernelGGL(k_gconv_up4, grid, dim3(256), 0, st, g_prof->recs.back().e0, g_prof->recs.back().e1, 0, a);
-        } else {
-            hipLaunchKernelGGL(k_gconv_up4, grid, dim3(256), 0, st, a);
-        }
+    if (a.form == 1 && a.Co == 32 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU) && (a.Ci == 32 || a.Ci == 64) &&
+        !getenv("SIGGAN_NO_UP4") && a.M / 128 >= (a.Ci == 32 ? 384 : 768) && a.M % 128 == 0 &&
+        ((1 << (a.lgHr + a.lgWr)) % 128) == 0 && a.lgWr >= 4 && a.lgWr <= 6) {
+        // all four parity classes per workgroup, input patch resident in LDS (k_gconv_up4): the short-K Generator blocks
+        dim3 grid(a.M / 128);
+        if (g_prof) g_prof->begin(5, 2.0 * a.M * a.Co * (double)(4 * a.Ci) * 4, st);
+        hipEvent_t e0 = g_prof ? g_prof->recs.back().e0 : nullptr, e1 = g_prof ? g_prof->recs.back().e1 : nullptr;
+        if (a.Ci == 32) hipExtLaunchKernelGGL(k_gconv_up4<32>, grid, dim3(256), 0, st, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL(k_gconv_up4<64>, grid, dim3(256), 0, st, e0, e1, 0, a);
         return;
     }
     const int ns = splits(blocks(128, 32));
