@@ -50,9 +50,12 @@ void launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s);
 // ---- Generator pieces ---------------------------------------------------------------------
 // y[n][f'] = z[n,:] . W[f,:] + b[f],  f' = hw*C0 + c  <->  f = c*16 + hw   (NHWC feature order)
 void launch_fc_pack(const float* W, float* Wt, int K, int C0, hipStream_t s);   // Wt[k][f'] = W[f][k]
-// bn_affine_relu != nullptr (eval): y = relu((z.Wt + b) * scale + shift) with [scale | shift] of the folded BatchNorm1d
+// bn_affine_relu != nullptr (eval): y = relu((z.Wt + b) * scale + shift) with [scale | shift] of the folded BatchNorm1d.
+// z == nullptr: z ~ N(0,1) is drawn inside the kernel (the values launch_randn(z_out, B*K, st, stream_id) would write) and
+// also stored to z_out
 void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s,
-                   const float* bn_affine_relu = nullptr);
+                   const float* bn_affine_relu = nullptr, const DevState* st = nullptr, uint32_t stream_id = 0,
+                   float* z_out = nullptr);
 // dW[f][k] = sum_n dy[n][f'] z[n][k];  db[f] = sum_n dy[n][f']
 void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s);
 

@@ -347,13 +347,37 @@ void launch_bn_bwd(float* da, const float* y, int64_t R, int C, float* bn, float
 // one thread = one feature f' x 8 batch rows; z rows broadcast from LDS; 20 weight loads in flight
 __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, const float* __restrict__ Wt,
                                                 const float* __restrict__ b, float* __restrict__ y, int B, int K, int C0,
-                                                const float* __restrict__ bn) {
+                                                const float* __restrict__ bn, const DevState* __restrict__ st, uint32_t sid,
+                                                float* __restrict__ z_out) {
     extern __shared__ float sz[];   // [8][K]
     const int F = C0 * 16;
     const int fp = blockIdx.x * 256 + threadIdx.x, nb = blockIdx.y * 8;
-    for (int i = threadIdx.x; i < 8 * K; i += 256) {
-        const int n = nb + i / K;
-        sz[i] = n < B ? z[(size_t)n * K + i % K] : 0.f;
+    if (z) {
+        for (int i = threadIdx.x; i < 8 * K; i += 256) {
+            const int n = nb + i / K;
+            sz[i] = n < B ? z[(size_t)n * K + i % K] : 0.f;
+        }
+    } else {
+        // z ~ N(0,1) drawn here: the block's 8 rows are elements [nb*K, nb*K + cnt) of the (B, K) tensor k_randn would
+        // fill (same Philox draw per group of four elements, same Box-Muller), also written out for the backward pass
+        const int64_t e0 = (int64_t)nb * K;                 // nb % 8 == 0: a multiple of 4
+        const int rows = B - nb < 8 ? B - nb : 8, cnt = rows * K;
+        for (int i = threadIdx.x; i < 2 * K; i += 256) {    // 8*K elements = 2*K groups of four
+            const int q = i * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (q < cnt) {
+                const uint4 r = draw(st, (uint64_t)(e0 / 4 + i), sid);
+                const float r0 = sqrtf(-2.0f * logf(u01(r.x))), r1 = sqrtf(-2.0f * logf(u01(r.z)));
+                const float a0 = 6.283185307179586f * u01(r.y), a1 = 6.283185307179586f * u01(r.w);
+                v[0] = r0 * cosf(a0); v[1] = r0 * sinf(a0); v[2] = r1 * cosf(a1); v[3] = r1 * sinf(a1);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = q + j < cnt;
+                sz[q + j] = in ? v[j] : 0.f;
+                if (in && z_out && blockIdx.x == 0) z_out[e0 + q + j] = v[j];
+            }
+        }
     }
     __syncthreads();
     if (fp >= F) return;
@@ -389,9 +413,9 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, con
         if (nb + j < B) y[(size_t)(nb + j) * F + fp] = acc[j] + bias;
 }
 void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s,
-                   const float* bn_affine_relu) {
+                   const float* bn_affine_relu, const DevState* st, uint32_t stream_id, float* z_out) {
     hipLaunchKernelGGL(k_fc_fwd, dim3(cdiv(C0 * 16, 256), cdiv(B, 8)), dim3(256), 8 * K * sizeof(float), s, z, Wt, b, y, B, K, C0,
-                       bn_affine_relu);
+                       bn_affine_relu, st, stream_id, z_out);
 }
 // dW[f][k] = sum_n dy[n][f'] * z[n][k],  db[f] = sum_n dy[n][f'].  A thread owns feature f' and a group of
 // FK latent columns: every dy value it loads feeds FK FMAs (z rows broadcast from LDS, 64 batch rows per

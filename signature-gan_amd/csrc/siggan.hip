@@ -402,13 +402,14 @@ static GConvArgs gconv_args(siggan_ctx* c) {
 
 // Generator.forward (generator_vanilla_gan.py:189-209).  training: BN batch stats (+ running
 // update) and raw pre-BN outputs kept for the backward pass; eval: BN folded into the epilogue.
+// z == nullptr: the latent batch is drawn inside the fc kernel from RNG stream rng_sid and left in z_out.
 static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s,
-                           float* partial = nullptr, float* slab_k = nullptr) {
+                           float* partial = nullptr, float* slab_k = nullptr, uint32_t rng_sid = 0, float* z_out = nullptr) {
     if (!partial) partial = c->partial;
     if (!training) {     // eval: BatchNorm1d + ReLU folded into the fc epilogue
-        launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->g_a[0], B, c->latent, c->gC[0], s, c->g_bne[0]);
+        launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->g_a[0], B, c->latent, c->gC[0], s, c->g_bne[0], c->dev, rng_sid, z_out);
     } else {
-        launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s);
+        launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s, nullptr, c->dev, rng_sid, z_out);
         launch_bn_train_stats(c->fc_y, B, c->F, GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), c->st.g_bn_running_mean,
                               c->st.g_bn_running_var, c->st.g_bn_batches, c->g_bn[0], partial, c->gC[0], BN_MOMENTUM,
                               BN_EPS, s);
@@ -585,8 +586,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // D(real) beside the Generator (train...py:309) -- unless the previous siggan_g_grads already ran it
     // (siggan_stage_real) beside its Generator backward; then bce only has to wait for that lane
     if (k.pre_real != 2) d_forward_rows(c, c->real_stage, 0, B, drop, L.a, c->slab_k2);
-    if (!k.has_z) launch_randn(c->z, (int64_t)B * c->latent, c->dev, 1, L.m);
-    g_forward_pass(c, c->z, B, false, c->img, L.m);                  // G.eval(), no grad (train...py:314-315)
+    g_forward_pass(c, k.has_z ? c->z : nullptr, B, false, c->img, L.m, nullptr, nullptr, 1, c->z);   // G.eval(), no grad (train...py:314-315)
     L.join(L.a);
     // siggan_step_begin: the G step's training forward depends on nothing the D step changes, so it
     // runs on its own lane beside D(fake) and the D step's backward (after the eval forward above: it
@@ -598,8 +598,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     if (k.pre_real == 2) (void)hipStreamWaitEvent(L.m, c->ev_dreal, 0);
     if (k.spec_g) {
         (void)hipStreamWaitEvent(c->s_c, e_spec, 0);
-        if (!k.has_zg) launch_randn(c->z_g, (int64_t)B * c->latent, c->dev, 2, c->s_c);
-        g_forward_pass(c, c->z_g, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2);
+        g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2, 2, c->z_g);
         (void)hipEventRecord(c->ev_gfwd, c->s_c);
     }
     d_backward_pass(c, L, c->real_stage, B, c->img, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0});
@@ -615,8 +614,7 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     } else {
         L.fork(L.a);
         repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
-        if (!k.has_z) launch_randn(c->z, (int64_t)B * c->latent, c->dev, 2, L.m);
-        g_forward_pass(c, c->z, B, true, c->img, L.m);               // G.train(): BN batch stats (train...py:349)
+        g_forward_pass(c, k.has_z ? c->z : nullptr, B, true, c->img, L.m, nullptr, nullptr, 2, c->z);   // G.train(): BN batch stats (train...py:349)
         L.join(L.a);
         zg = c->z; img = c->img;
     }
@@ -994,6 +992,8 @@ extern "C" int siggan_debug_tensor(siggan_ctx* c, const char* name, int32_t idx,
     else if (!strcmp(name, "g_da") && gl) { *ptr = c->g_da[idx]; *cap = gsz(idx); }
     else if (!strcmp(name, "d_a") && dl) { *ptr = c->d_a[idx]; *cap = dsz(idx); }
     else if (!strcmp(name, "d_dv") && dl) { *ptr = c->d_dv[idx]; *cap = dsz(idx); }
+    else if (!strcmp(name, "z")) { *ptr = c->z; *cap = Bm * c->latent; }
+    else if (!strcmp(name, "z_g")) { *ptr = c->z_g; *cap = Bm * c->latent; }
     else if (!strcmp(name, "img")) { *ptr = c->img; *cap = Bm * SS; }
     else if (!strcmp(name, "dpre")) { *ptr = c->dpre; *cap = Bm * SS; }
     else if (!strcmp(name, "logits")) { *ptr = c->logits; *cap = Bd; }

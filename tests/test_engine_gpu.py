@@ -240,3 +240,24 @@ def test_staged_next_batch_is_bitwise_identical():
         assert mets == ref_mets, kind
         for a, b in zip(ref_state, state):
             assert torch.equal(a, b), f"{kind}: staging the next batch changed the result"
+
+
+def test_latent_drawn_inside_the_fc_kernel():
+    """Without an explicit z the fc kernel draws the latent batch itself (no separate RNG launch) and leaves it in the
+    workspace for the backward pass: it must be standard normal, and feeding the same values back as an explicit z must
+    reproduce the step bit for bit."""
+    from hipcommon import cuda, make_engine
+    size, latent, batch = 64, 100, 64
+    e1 = make_engine(size, latent, batch, warm=True)
+    e1.seed(99)
+    m1 = e1.g_step(batch, clip=0.5)
+    z = e1.debug_tensor("z", 0, (batch, latent)).clone()
+    assert torch.isfinite(z).all() and abs(float(z.mean())) < 0.05 and abs(float(z.std()) - 1.0) < 0.05
+    assert float(z.abs().max()) < 6.0 and len(torch.unique(z)) > 0.99 * z.numel()
+    e2 = make_engine(size, latent, batch, warm=True)
+    e2.seed(99)
+    m2 = e2.g_step(batch, z, clip=0.5)
+    assert m1 == m2
+    for a, b in zip((e1.g_params, e1.g_exp_avg_sq, e1.g_bn_mean), (e2.g_params, e2.g_exp_avg_sq, e2.g_bn_mean)):
+        assert torch.equal(a, b)
+    e1.close(); e2.close()
