@@ -17,7 +17,6 @@
 // t+1 are issued before the MFMAs of tile t, written to the other LDS buffer after them).
 #include "gconv.h"
 #include <hip/hip_ext.h>
-#include <stdlib.h>
 
 namespace siggan {
 
@@ -482,7 +481,7 @@ void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         return launch_cfg<64, 64, 2, 2>(a, st, 2, ns);
     }
     if (a.form == 1 && a.Co == 32 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU) && (a.Ci == 32 || a.Ci == 64) &&
-        !getenv("SIGGAN_NO_UP4") && a.M / 128 >= (a.Ci == 32 ? 384 : 768) && a.M % 128 == 0 &&
+        a.M / 128 >= (a.Ci == 32 ? 384 : 768) && a.M % 128 == 0 &&
         ((1 << (a.lgHr + a.lgWr)) % 128) == 0 && a.lgWr >= 4 && a.lgWr <= 6) {
         // all four parity classes per workgroup, input patch resident in LDS (k_gconv_up4): the short-K Generator blocks
         dim3 grid(a.M / 128);
