@@ -52,6 +52,9 @@ class VanillaGAN(nn.Module):
         self.latent_dim, self.image_size, self.image_channels = latent_dim, image_size, image_channels
         self.g_lr, self.d_lr, self.beta1, self.beta2 = g_lr, d_lr, beta1, beta2
         self.label_smoothing, self.use_spectral_norm = label_smoothing, use_spectral_norm
+        if use_spectral_norm:
+            raise NotImplementedError("training with a spectral-norm Discriminator is not built (SURVEY 8f-4); the stand-alone "
+                                      "Discriminator(use_spectral_norm=True) loads and scores such checkpoints in eval mode")
         if device is None:
             device = "cuda" if torch.cuda.is_available() else "cpu"
         self._device = torch.device(device)

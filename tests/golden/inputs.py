@@ -42,6 +42,24 @@ def gen_state(specs, seed: int) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
+def gen_sn_state(d_specs, seed: int) -> "OrderedDict[str, np.ndarray]":
+    """State of a spectral-norm Discriminator (torch.nn.utils.spectral_norm keys) from the plain specs: every
+    '<m>.weight' becomes '<m>.weight_orig' (same values as gen_state would give '<m>.weight'), plus unit vectors
+    '<m>.weight_u' (rows) and '<m>.weight_v' (columns of the weight viewed as a matrix)."""
+    plain = gen_state(d_specs, seed)
+    out = OrderedDict()
+    for name, a in plain.items():
+        if name.endswith(".weight"):
+            base = name[:-len("weight")]
+            out[base + "weight_orig"] = a
+            for tag, n in (("weight_u", a.shape[0]), ("weight_v", int(np.prod(a.shape[1:])))):
+                v = rng(seed, base + tag).standard_normal(n)
+                out[base + tag] = (v / np.linalg.norm(v)).astype(np.float32)
+        else:
+            out[name] = a
+    return out
+
+
 def gen_adam(specs, seed: int):
     """Warm Adam moments for every 'param' entry: (exp_avg, exp_avg_sq, step)."""
     m, v = OrderedDict(), OrderedDict()

@@ -254,6 +254,32 @@ def make(size, latent, B, full_image):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_spectral_norm():
+    """(x) spectral-norm Discriminator, eval mode (no power iteration): probabilities, feature probe, state_dict keys."""
+    from collections import OrderedDict
+    from discriminator_vanilla_gan import Discriminator
+    out = {}
+    for size in (64, 128):
+        d = Discriminator(input_size=size, use_spectral_norm=True).eval()
+        specs = OrderedDict((k, (tuple(v.shape), "param")) for k, v in Discriminator(input_size=size).state_dict().items())
+        state = I.gen_sn_state(specs, SEED_STATE_D)
+        sd = d.state_dict()
+        assert set(sd) == set(state), (sorted(set(sd) ^ set(state)))
+        d.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        x = torch.from_numpy(I.gen_real(4, size, SEED_REAL))
+        with torch.no_grad():
+            p = d(x)
+            f = d.forward_features(x)
+        out[f"s{size}/probs"] = p.reshape(-1).numpy()
+        ff = f.reshape(-1).numpy()
+        out[f"s{size}/feat_probe"] = ff[I.probe_idx(ff.size, "feat", 256)]
+        out[f"s{size}/keys"] = np.array(json.dumps([[k, list(v.shape)] for k, v in sd.items()]))
+    out["meta"] = np.array(json.dumps({"torch": torch.__version__, "seed_state_d": SEED_STATE_D, "seed_real": SEED_REAL}))
+    path = os.path.join(HERE, "golden_spectral_norm.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def checkpoint_manifests():
     """(ix) structure of the two checkpoint layouts (keys, shapes, dtypes) -- no weights."""
     man = {}
@@ -287,6 +313,9 @@ if __name__ == "__main__":
     if "--manifest-only" in sys.argv:
         checkpoint_manifests()
         sys.exit(0)
+    if "--spectral-norm" in sys.argv:
+        make_spectral_norm()
+        sys.exit(0)
     if "--case" in sys.argv:                      # one more fixture: --case SIZE LATENT BATCH
         k = sys.argv.index("--case")
         make(int(sys.argv[k + 1]), int(sys.argv[k + 2]), int(sys.argv[k + 3]), full_image=False)
@@ -296,4 +325,5 @@ if __name__ == "__main__":
     make(128, 128, 4, full_image=False)
     make(128, 128, 32, full_image=False)
     make(64, 100, 128, full_image=False)          # BASELINE configs[3]: conv G/D 64x64, batch 128
+    make_spectral_norm()
     checkpoint_manifests()
