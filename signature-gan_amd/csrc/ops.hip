@@ -495,10 +495,12 @@ __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ act
     constexpr int RY = 4, C = 32;
     const int c4 = threadIdx.x & 7;
     const StripId t = strip_of<RY>(blockIdx.x, S, threadIdx.x >> 3);
+    __shared__ __attribute__((aligned(16))) float sw9[9 * 36];     // W[c][tap] -> [tap][c] (row stride 36), one coalesced pass
+    for (int i = threadIdx.x; i < 9 * 32; i += 256) sw9[(i % 9) * 36 + i / 9] = W[i];
+    __syncthreads();
     f4v w[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-        w[k] = f4v{W[(c4 * 4 + 0) * 9 + k], W[(c4 * 4 + 1) * 9 + k], W[(c4 * 4 + 2) * 9 + k], W[(c4 * 4 + 3) * 9 + k]};
+    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f4v*>(sw9 + k * 36 + c4 * 4);
     const float bias = b[0];
     const float* base = act + (size_t)t.n * S * S * C + c4 * 4;
     f4v v[RY + 2][3];
@@ -572,10 +574,12 @@ __global__ __launch_bounds__(256) void k_final_bnbwd_reduce(const float* __restr
     constexpr int RY = 8, C = 32;
     __shared__ f4v sh[2][4][8];
     const int c4 = threadIdx.x & 7, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float sw9[9 * 36];     // W[c][tap] -> [tap][c] (row stride 36), one coalesced pass
+    for (int i = threadIdx.x; i < 9 * 32; i += 256) sw9[(i % 9) * 36 + i / 9] = W[i];
+    __syncthreads();
     f4v w[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-        w[k] = f4v{W[(c4 * 4 + 0) * 9 + k], W[(c4 * 4 + 1) * 9 + k], W[(c4 * 4 + 2) * 9 + k], W[(c4 * 4 + 3) * 9 + k]};
+    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f4v*>(sw9 + k * 36 + c4 * 4);
     const f4v sc = ldg4(bn + c4 * 4), sf = ldg4(bn + C + c4 * 4), mu = ldg4(bn + 2 * C + c4 * 4), rs = ldg4(bn + 3 * C + c4 * 4);
     f4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     for (int sid = blockIdx.x; sid < nstrips; sid += gridDim.x) {
@@ -618,10 +622,12 @@ __global__ __launch_bounds__(256) void k_final_bnbwd_apply(const float* __restri
     constexpr int RY = 4, C = 32;
     const int c4 = threadIdx.x & 7;
     const StripId t = strip_of<RY>(blockIdx.x, S, threadIdx.x >> 3);
+    __shared__ __attribute__((aligned(16))) float sw9[9 * 36];     // W[c][tap] -> [tap][c] (row stride 36), one coalesced pass
+    for (int i = threadIdx.x; i < 9 * 32; i += 256) sw9[(i % 9) * 36 + i / 9] = W[i];
+    __syncthreads();
     f4v w[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-        w[k] = f4v{W[(c4 * 4 + 0) * 9 + k], W[(c4 * 4 + 1) * 9 + k], W[(c4 * 4 + 2) * 9 + k], W[(c4 * 4 + 3) * 9 + k]};
+    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f4v*>(sw9 + k * 36 + c4 * 4);
     const f4v sc = ldg4(bn + c4 * 4), sf = ldg4(bn + C + c4 * 4), mu = ldg4(bn + 2 * C + c4 * 4), rs = ldg4(bn + 3 * C + c4 * 4);
     const f4v c1 = ldg4(bn + 4 * C + c4 * 4), c2 = ldg4(bn + 5 * C + c4 * 4);
     float d[RY + 2][3];
@@ -763,18 +769,19 @@ __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x0,
                                                    float* __restrict__ out, int S) {
     constexpr int RY = 2, C = 64;
     __shared__ float sx[(2 * RY + 2) * 130];
+    __shared__ __attribute__((aligned(16))) float sw[16 * (C + 4)];  // weights transposed to [tap][co] (row stride C + 4: conflict-free both ways)
     const int Ho = S >> 1, nby = Ho / RY, Wp = S + 2;
     const int n = blockIdx.x / nby, oh0 = (blockIdx.x % nby) * RY;
     const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
     stage_x<RY>(sx, seg_ptr(x0, n0, x1, n, S), oh0, S);
-    f4v w[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-        w[t] = f4v{W[(q * 4 + 0) * 16 + t], W[(q * 4 + 1) * 16 + t], W[(q * 4 + 2) * 16 + t], W[(q * 4 + 3) * 16 + t]};
+    for (int i = threadIdx.x; i < 16 * C; i += 256) sw[(i & 15) * (C + 4) + (i >> 4)] = W[i];
     const f4v bias = ldg4(b + q * 4);
     f4v nz = {1.f, 1.f, 1.f, 1.f};
     if (noise) nz = ldg4(noise + (size_t)n * C + q * 4);
     __syncthreads();
+    f4v w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const f4v*>(sw + t * (C + 4) + q * 4);
     for (int p = pl; p < RY * Ho; p += 16) {
         const int r = p / Ho, ow = p - r * Ho;
         const float* xr = sx + (2 * r) * Wp + 2 * ow;
@@ -883,10 +890,12 @@ __global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const float* __restric
     int bid = blockIdx.x;
     const int b = (bid % nbb) * 16 + bl; bid /= nbb;
     const int a0 = (bid % nba) * RA, n = bid / nba;
+    __shared__ __attribute__((aligned(16))) float sw[16 * (C + 4)];  // W[co][tap] -> [tap][co] (row stride C + 4), one coalesced pass
+    for (int i = threadIdx.x; i < 16 * C; i += 256) sw[(i & 15) * (C + 4) + (i >> 4)] = W[i];
+    __syncthreads();
     f4v w[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
-        w[t] = f4v{W[(q * 4 + 0) * 16 + t], W[(q * 4 + 1) * 16 + t], W[(q * 4 + 2) * 16 + t], W[(q * 4 + 3) * 16 + t]};
+    for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const f4v*>(sw + t * (C + 4) + q * 4);
     const float* base = dv + (size_t)n * Ho * Ho * C + q * 4;
     f4v g[RA + 2][3];
 #pragma unroll
