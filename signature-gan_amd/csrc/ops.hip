@@ -344,7 +344,7 @@ void launch_bn_bwd(float* da, const float* y, int64_t R, int C, float* bn, float
 // Generator fc (latent x weight) -- K = latent_dim is tiny; one thread per output
 // =========================================================================================
 // (Wt[k][f'] = W[f][k] is the k-major copy k_prepare keeps in the NHWC feature order, so lanes walk f' coalesced)
-// one thread = one feature f' x 8 batch rows; z rows broadcast from LDS; 20 weight loads in flight
+// one thread = one feature f' x 8 batch rows; z rows broadcast from LDS; 50 weight loads in flight
 __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, const float* __restrict__ Wt,
                                                 const float* __restrict__ b, float* __restrict__ y, int B, int K, int C0,
                                                 const float* __restrict__ bn, const DevState* __restrict__ st, uint32_t sid,
@@ -386,12 +386,21 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, con
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     const float* wp = Wt + fp;
     int k = 0;
-    for (; k + 20 <= K; k += 20) {
-        float w[20];
+    for (; k + 50 <= K; k += 50) {                   // 50 weight loads in flight (the latent size is 100 or 128)
+        float w[50];
 #pragma unroll
-        for (int u = 0; u < 20; ++u) w[u] = wp[(size_t)(k + u) * F];
+        for (int u = 0; u < 50; ++u) w[u] = wp[(size_t)(k + u) * F];
 #pragma unroll
-        for (int u = 0; u < 20; ++u)
+        for (int u = 0; u < 50; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(sz[j * K + k + u], w[u], acc[j]);
+    }
+    for (; k + 14 <= K; k += 14) {
+        float w[14];
+#pragma unroll
+        for (int u = 0; u < 14; ++u) w[u] = wp[(size_t)(k + u) * F];
+#pragma unroll
+        for (int u = 0; u < 14; ++u)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(sz[j * K + k + u], w[u], acc[j]);
     }
@@ -1052,22 +1061,28 @@ void launch_cls_bwd(const float* logits, int n0, float y0, float y1, const float
     const int64_t total = (int64_t)B * 16 * C;
     hipLaunchKernelGGL(k_cls_bwd, dim3(cdiv(total, 256)), dim3(256), 0, s, logits, B, n0, y0, y1, wcp, act, noise, slope, dv, total, C);
 }
-__global__ void k_cls_wgrad(const float* __restrict__ dlogit, const float* __restrict__ act, float* __restrict__ dWc,
+// dWc[f] = sum_n dlogit[n] * act[n][f'], dbc = sum_n dlogit[n]: 64 features x 4 row lanes per block (rows n = lane, lane + 4,
+// ...), the four partial sums are added in lane order through LDS
+__global__ __launch_bounds__(256) void k_cls_wgrad(const float* __restrict__ dlogit, const float* __restrict__ act, float* __restrict__ dWc,
                             float* __restrict__ dbc, int B, int C) {
+    __shared__ float sh[4][64];
     const int F = 16 * C;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > F) return;
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     float acc = 0.f;
     if (j < F) {
-        for (int n = 0; n < B; ++n) acc = fmaf(dlogit[n], act[(size_t)n * F + j], acc);
-        dWc[(j % C) * 16 + j / C] = acc;
-    } else {
-        for (int n = 0; n < B; ++n) acc += dlogit[n];
-        dbc[0] = acc;
+#pragma unroll 8
+        for (int n = rl; n < B; n += 4) acc = fmaf(dlogit[n], act[(size_t)n * F + j], acc);
+    } else if (j == F) {
+        for (int n = rl; n < B; n += 4) acc += dlogit[n];
     }
+    sh[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl != 0 || j > F) return;
+    const float t = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+    if (j < F) dWc[(j % C) * 16 + j / C] = t; else dbc[0] = t;
 }
 void launch_cls_wgrad(const float* dlogit, const float* act, float* dWc, float* dbc, int B, int C, hipStream_t s) {
-    hipLaunchKernelGGL(k_cls_wgrad, dim3(cdiv(16 * C + 1, 256)), dim3(256), 0, s, dlogit, act, dWc, dbc, B, C);
+    hipLaunchKernelGGL(k_cls_wgrad, dim3(cdiv(16 * C + 1, 64)), dim3(256), 0, s, dlogit, act, dWc, dbc, B, C);
 }
 
 // =========================================================================================
