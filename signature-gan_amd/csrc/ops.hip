@@ -822,7 +822,7 @@ void launch_conv1_fwd(const float* x0, int n0, const float* x1, const float* W, 
 __global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ dv, const float* __restrict__ x0, int n0,
                                                      const float* __restrict__ x1, float* __restrict__ partial, int S,
                                                      int nstrips) {
-    constexpr int RY = 4, C = 64;
+    constexpr int RY = 8, C = 64;
     __shared__ float sx[(2 * RY + 2) * 130];
     __shared__ float sh[4][16][69];
     const int Ho = S >> 1, nby = Ho / RY, Wp = S + 2;
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ d
 }
 void launch_conv1_wgrad(const float* dv, const float* x0, int n0, const float* x1, float* dW, float* db, float* partial,
                         int B, int S, int C, hipStream_t s) {
-    const int nstrips = B * (S / 2 / 4);
+    const int nstrips = B * (S / 2 / 8);
     const int nch = nstrips < 1024 ? nstrips : 1024;
     hipLaunchKernelGGL(k_conv1_wgrad, dim3(nch), dim3(256), 0, s, dv, x0, n0, x1, partial, S, nstrips);
     hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 17, 64)), dim3(1024), 0, s, partial, nch, C * 17, dW, C * 16, db);
