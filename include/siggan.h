@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SIGGAN_ABI_VERSION 2   /* 2: siggan_stage_real, siggan_augment_batch */
+#define SIGGAN_ABI_VERSION 3   /* 2: siggan_stage_real, siggan_augment_batch; 3: siggan_config.dtype, siggan_rng_state, siggan_comm_* */
 
 enum {
     SIGGAN_OK = 0,
@@ -68,7 +68,17 @@ typedef struct siggan_config {
     float   dropout;        /* Discriminator dropout p (default 0.25) */
     float   leaky_slope;    /* LeakyReLU slope (default 0.2) */
     uint64_t seed;          /* seed of the library's counter-based RNG (z, dropout masks) */
+    int32_t dtype;          /* SIGGAN_DTYPE_*: storage type of the library-owned activations / activation gradients and of
+                             * the weight copies the MFMA kernels read.  F32 (0) is the reference's arithmetic and the parity
+                             * path.  BF16 / F16 are build-defined narrow variants (BASELINE.json configs[2] / configs[4]; the
+                             * reference has no reduced-precision mode, vanilla_gan_model.py:107-120): 16-bit storage, 16-bit
+                             * MFMA operands, fp32 accumulation, fp32 master weights / BatchNorm statistics / losses / weight
+                             * gradients / Adam.  Every caller-visible tensor stays fp32 in all modes. */
+    float   f16_grad_scale; /* F16 only: power-of-two factor carried by the backward chains so that small activation
+                             * gradients stay above the fp16 subnormals; removed again inside the optimiser step (the bound
+                             * *_grads arenas hold scale x gradient between *_grads and *_apply).  0 = default (1024). */
 } siggan_config;
+enum { SIGGAN_DTYPE_F32 = 0, SIGGAN_DTYPE_BF16 = 1, SIGGAN_DTYPE_F16 = 2 };
 
 /* Borrowed storage.  *_params / *_grads / *_exp_avg / *_exp_avg_sq: flat fp32 arenas holding
  * the network's parameters() in reference order (sizes: siggan_param_count).  *_adam_steps: one
@@ -120,6 +130,10 @@ int siggan_bind(siggan_ctx *ctx, const siggan_storage *st);
  * (load_state_dict, manual edits): packed weight copies are rebuilt on next use */
 int siggan_params_changed(siggan_ctx *ctx);
 int siggan_seed(siggan_ctx *ctx, uint64_t seed, uint64_t offset);
+/* reads the RNG position back (seed, call counter): a caller that re-creates a context (larger max_batch) or resumes a
+ * run hands them to siggan_seed so the z / dropout stream continues instead of restarting; the reference's equivalent is
+ * torch's global generator, which simply keeps running (train_vanilla_gan_signatures.py:313,356).  Synchronises. */
+int siggan_rng_state(siggan_ctx *ctx, uint64_t *seed, uint64_t *offset);
 /* execution mode of the step phases (default: SIGGAN_MODE_OVERLAP): SIGGAN_MODE_GRAPH replays each phase as a
  * hipGraph captured once per distinct (batch, flags, hyper-parameters); SIGGAN_MODE_OVERLAP runs
  * the weight-gradient / reduction kernels on side streams beside the input-gradient chain. */
@@ -184,18 +198,19 @@ int siggan_g_apply(siggan_ctx *ctx, const siggan_hyper *hp, float *metrics_dev, 
                    void *stream);
 
 /* ---- operator-level entry points (tests, profiling) --------------------------------------- */
-/* All tensors NHWC fp32 on the device.  4x4 stride-2 pad-1 convolution family on MFMA:
+/* Activation tensors NHWC on the device in the CONTEXT's element type (fp32, or bf16 / f16 for a narrow context);
+ * weights and weight gradients always fp32 in the reference's layouts.  4x4 stride-2 pad-1 convolution family on MFMA:
  *   form 0 "down": out[n,oh,ow,co] = sum_{kh,kw,ci} in[n,2oh-1+kh,2ow-1+kw,ci] * w[co,ci,kh,kw]
  *                  (Conv2d forward; ConvTranspose2d input-gradient)            w is (Cout,Cin,4,4)
  *   form 1 "up"  : out[n,oh,ow,co] = sum_{ci,kh,kw: oh=2ih-1+kh} in[n,ih,iw,ci] * w[ci,co,kh,kw]
  *                  (ConvTranspose2d forward; Conv2d input-gradient)            w is (Cin,Cout,4,4)
  * w_dev is in the reference's (torch) layout; the library packs it. */
-int siggan_op_conv4x4s2(siggan_ctx *ctx, int32_t form, const float *in_dev, const float *w_dev,
-                        float *out_dev, int32_t batch, int32_t h_in, int32_t c_in, int32_t c_out,
+int siggan_op_conv4x4s2(siggan_ctx *ctx, int32_t form, const void *in_dev, const float *w_dev,
+                        void *out_dev, int32_t batch, int32_t h_in, int32_t c_in, int32_t c_out,
                         void *stream);
 /* weight gradient of the same family: dw[cs,cl,kh,kw] = sum_{n,p,q} small[n,p,q,cs] *
  * large[n,2p-1+kh,2q-1+kw,cl]; dw_dev in torch layout (Cs,Cl,4,4). */
-int siggan_op_conv4x4s2_wgrad(siggan_ctx *ctx, const float *small_dev, const float *large_dev,
+int siggan_op_conv4x4s2_wgrad(siggan_ctx *ctx, const void *small_dev, const void *large_dev,
                               float *dw_dev, int32_t batch, int32_t h_small, int32_t c_small,
                               int32_t c_large, void *stream);
 /* fused Adam over a flat arena (torch.optim.Adam single step, step = count AFTER increment) */
@@ -228,7 +243,7 @@ int32_t siggan_prof_slots(void);
 int siggan_prof_read(siggan_ctx *ctx, int32_t idx, char *name, int32_t name_cap, int64_t *launches,
                      double *ms, double *flops);
 
-/* test hook: copy the first n floats of a library-owned workspace tensor (NHWC) into out_dev:
+/* test hook: copy the first n elements of a library-owned workspace tensor (NHWC), converted to fp32, into out_dev:
  * "g_y"/"g_a"/"g_da" (layer 0..Lg), "d_a"/"d_dv" (block 1..Ld), "img", "dpre", "logits",
  * "probs", "dlogit".  Used by tests that localise a parity failure. */
 int siggan_debug_tensor(siggan_ctx *ctx, const char *name, int32_t index, float *out_dev, int64_t n, void *stream);

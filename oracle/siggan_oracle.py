@@ -124,14 +124,75 @@ def _act(x: Tensor, slope: float, given: Optional[Tensor], record: Optional[list
     return _ActWithGivenSign.apply(x, given.reshape(x.shape), slope)
 
 
+class _RoundFwd(torch.autograd.Function):
+    """value rounded to a narrow float type, gradient passed through: a tensor the HIP path STORES in that type."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        return x.to(dtype).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _RoundBwd(torch.autograd.Function):
+    """identity whose GRADIENT is rounded to a narrow float type (times a power-of-two scale, as the fp16 chains carry
+    it): a gradient tensor the HIP path stores in that type."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, scale):
+        ctx.dtype, ctx.scale = dtype, scale
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g * ctx.scale).to(ctx.dtype).to(torch.float32) / ctx.scale, None, None
+
+
+class Quant:
+    """Storage-rounding model of the build-defined bf16 / f16 variants (BASELINE.json configs[2] / configs[4]; the
+    reference itself is fp32-only, vanilla_gan_model.py:107-120).  The arithmetic stays fp32; what is rounded to
+    ``dtype`` is exactly what the HIP path keeps in 16 bits: ``a`` -- a stored activation, ``g`` -- a stored activation
+    gradient (marks the tensor whose incoming gradient is stored), ``w`` -- the weight copy an MFMA convolution reads
+    (the gradient flows to the fp32 master weight unchanged).  With a Quant the oracle predicts the narrow path up to
+    fp32 summation order; without one it is the fp32 reference arithmetic the narrow path is compared against at a
+    stated looser tolerance."""
+
+    def __init__(self, dtype: torch.dtype, grad_scale: float = 1.0):
+        self.dtype, self.grad_scale = dtype, float(grad_scale)
+
+    def a(self, x):
+        return _RoundFwd.apply(x, self.dtype)
+
+    def g(self, x):
+        return _RoundBwd.apply(x, self.dtype, self.grad_scale)
+
+    def w(self, w):
+        return _RoundFwd.apply(w, self.dtype)
+
+
+class _NoQuant:
+    a = g = w = staticmethod(lambda x: x)
+
+
+_NOQ = _NoQuant()
+
+
 def g_forward(sd: Dict[str, Tensor], z: Tensor, training: bool, size: int,
-              signs: Optional[Sequence[Tensor]] = None, record: Optional[list] = None) -> Tensor:
+              signs: Optional[Sequence[Tensor]] = None, record: Optional[list] = None,
+              q: Optional[Quant] = None) -> Tensor:
     """Generator.forward (generator_vanilla_gan.py:189-209).  ``training`` selects the
     BatchNorm mode; in training mode running stats / num_batches_tracked in ``sd`` are
     updated in place exactly as nn.BatchNorm does (momentum 0.1, unbiased running var).
     ``signs`` / ``record``: see _ActWithGivenSign (one entry per ReLU, NCHW bool)."""
     chain = G_CHAIN[size]
     sg = (lambda i: None) if signs is None else (lambda i: signs[i])
+    q = q or _NOQ
+    # the pre-BatchNorm tensor is kept (for the backward pass) only in training mode; in eval mode BatchNorm is folded
+    # into the producing kernel's epilogue and only the activation is stored
+    qy = (lambda t: q.g(q.a(t))) if training else (lambda t: t)
+    n_blocks = len(chain) - 1
 
     def bn(x, prefix):
         if training:
@@ -140,13 +201,15 @@ def g_forward(sd: Dict[str, Tensor], z: Tensor, training: bool, size: int,
                             sd[prefix + "weight"], sd[prefix + "bias"],
                             training, BN_MOMENTUM, BN_EPS)
 
-    x = F.linear(z, sd["fc.0.weight"], sd["fc.0.bias"])
-    x = _act(bn(x, "fc.1."), 0.0, sg(0), record)
+    x = qy(F.linear(z, sd["fc.0.weight"], sd["fc.0.bias"]))
+    x = q.g(q.a(_act(bn(x, "fc.1."), 0.0, sg(0), record)))
     x = x.view(-1, chain[0], 4, 4)
-    for i in range(len(chain) - 1):
+    for i in range(n_blocks):
         p = f"upsample_blocks.{i}.block."
-        x = F.conv_transpose2d(x, sd[p + "0.weight"], None, stride=2, padding=1)
-        x = _act(bn(x, p + "1."), 0.0, sg(i + 1), record)
+        x = qy(F.conv_transpose2d(x, q.w(sd[p + "0.weight"]), None, stride=2, padding=1))
+        x = q.a(_act(bn(x, p + "1."), 0.0, sg(i + 1), record))
+        if i + 1 < n_blocks:            # the last block's activation gradient is consumed where it is formed, never stored
+            x = q.g(x)
     x = F.conv2d(x, sd["final_conv.0.weight"], sd["final_conv.0.bias"], stride=1, padding=1)
     return torch.tanh(x)
 
@@ -154,24 +217,28 @@ def g_forward(sd: Dict[str, Tensor], z: Tensor, training: bool, size: int,
 def d_features(sd: Dict[str, Tensor], x: Tensor, size: int,
                masks: Optional[Sequence[Tensor]] = None,
                dropout: float = 0.25, slope: float = 0.2,
-               signs: Optional[Sequence[Tensor]] = None, record: Optional[list] = None) -> Tensor:
+               signs: Optional[Sequence[Tensor]] = None, record: Optional[list] = None,
+               q: Optional[Quant] = None) -> Tensor:
     """Discriminator.forward_features (discriminator_vanilla_gan.py:262-274).  ``masks`` is a
     list of (B, C_i) keep masks (1 keep / 0 drop), one per block, standing in for the hidden
     RNG of nn.Dropout2d (:74-75); None means eval mode (dropout off)."""
     n_blocks = len(D_CHAIN[size])
+    q = q or _NOQ
     for i in range(n_blocks):
         p = f"conv_blocks.{i}.block.0."
-        x = F.conv2d(x, sd[p + "weight"], sd[p + "bias"], stride=2, padding=1)
+        w = sd[p + "weight"] if i == 0 else q.w(sd[p + "weight"])      # block 1 (Cin = 1) is not an MFMA kernel: fp32 weights
+        x = q.g(F.conv2d(x, w, sd[p + "bias"], stride=2, padding=1))   # stored gradient: d(pre-activation)
         x = _act(x, slope, None if signs is None else signs[i], record)
         if masks is not None and dropout > 0:
             noise = masks[i].to(x.dtype) / (1.0 - dropout)     # bernoulli(1-p).div_(1-p)
             x = x * noise[:, :, None, None]
+        x = q.a(x)                                                       # stored activation: after LeakyReLU + dropout
     return x.flatten(1)
 
 
-def d_forward(sd, x, size, masks=None, dropout=0.25, slope=0.2, signs=None, record=None) -> Tensor:
+def d_forward(sd, x, size, masks=None, dropout=0.25, slope=0.2, signs=None, record=None, q=None) -> Tensor:
     """Discriminator.forward (:241-260): probabilities (B,1)."""
-    f = d_features(sd, x, size, masks, dropout, slope, signs, record)
+    f = d_features(sd, x, size, masks, dropout, slope, signs, record, q)
     return torch.sigmoid(F.linear(f, sd["classifier.0.weight"], sd["classifier.0.bias"]))
 
 
@@ -232,19 +299,19 @@ def _leafs(sd, names):
 
 
 def d_grads(g_sd, d_sd, real: Tensor, z: Tensor, masks_real, masks_fake, size: int,
-            label_smoothing: float = 0.9, dropout: float = 0.25, signs=None, record=None):
+            label_smoothing: float = 0.9, dropout: float = 0.25, signs=None, record=None, q=None):
     """Forward/backward half of the D step (vanilla_gan_model.py:204-233 ==
     train_vanilla_gan_signatures.py:294-323): returns (metrics, grads, real_preds, fake_preds,
     fake_images).  G runs in eval mode under no_grad; only D parameters receive gradients."""
     names = param_names(d_state_specs(size, real.shape[1]))
     leaf = _leafs(d_sd, names)
     with torch.no_grad():
-        fake = g_forward(g_sd, z, training=False, size=size)
+        fake = g_forward(g_sd, z, training=False, size=size, q=q)
     nb = len(D_CHAIN[size])
     s_real, s_fake = (None, None) if signs is None else (signs[:nb], signs[nb:])
-    real_preds = d_forward(leaf, real, size, masks_real, dropout, signs=s_real, record=record)
+    real_preds = d_forward(leaf, real, size, masks_real, dropout, signs=s_real, record=record, q=q)
     loss_real = bce(real_preds, label_smoothing)
-    fake_preds = d_forward(leaf, fake, size, masks_fake, dropout, signs=s_fake, record=record)
+    fake_preds = d_forward(leaf, fake, size, masks_fake, dropout, signs=s_fake, record=record, q=q)
     loss_fake = bce(fake_preds, 0.0)
     loss = loss_real + loss_fake
     gl = torch.autograd.grad(loss, [leaf[k] for k in names])
@@ -260,7 +327,7 @@ def d_grads(g_sd, d_sd, real: Tensor, z: Tensor, masks_real, masks_fake, size: i
     return metrics, grads, real_preds.detach(), fake_preds.detach(), fake
 
 
-def g_grads(g_sd, d_sd, z: Tensor, size: int, signs=None, record=None):
+def g_grads(g_sd, d_sd, z: Tensor, size: int, signs=None, record=None, q=None):
     """Forward/backward half of the G step (vanilla_gan_model.py:274-297 ==
     train_vanilla_gan_signatures.py:349-365): G in train mode (BN batch statistics, running
     stats updated in ``g_sd``), D in eval mode (dropout off), BCE against 1.0 (no smoothing)."""
@@ -269,11 +336,11 @@ def g_grads(g_sd, d_sd, z: Tensor, size: int, signs=None, record=None):
     leaf.update(_leafs(g_sd, names))
     ng = len(G_CHAIN[size])
     s_g, s_d = (None, None) if signs is None else (signs[:ng], signs[ng:])
-    fake = g_forward(leaf, z, training=True, size=size, signs=s_g, record=record)
+    fake = g_forward(leaf, z, training=True, size=size, signs=s_g, record=record, q=q)
     for k in g_sd:                      # running stats / counters were updated on the copies
         if k not in names:
             g_sd[k] = leaf[k]
-    fake_preds = d_forward(d_sd, fake, size, None, signs=s_d, record=record)
+    fake_preds = d_forward(d_sd, fake, size, None, signs=s_d, record=record, q=q)
     loss = bce(fake_preds, 1.0)
     gl = torch.autograd.grad(loss, [leaf[k] for k in names])
     grads = {k: g.detach() for k, g in zip(names, gl)}
@@ -284,17 +351,17 @@ def g_grads(g_sd, d_sd, z: Tensor, size: int, signs=None, record=None):
 
 def d_step(g_sd, d_sd, d_opt: AdamState, real, z, masks_real, masks_fake, size,
            lr=2e-4, beta1=0.5, beta2=0.999, label_smoothing=0.9, clip: Optional[float] = None,
-           dropout: float = 0.25, signs=None, record=None):
+           dropout: float = 0.25, signs=None, record=None, q=None):
     metrics, grads, rp, fp, fake = d_grads(g_sd, d_sd, real, z, masks_real, masks_fake, size,
-                                           label_smoothing, dropout, signs, record)
+                                           label_smoothing, dropout, signs, record, q)
     metrics["d_grad_norm"] = clip_grad_norm(list(grads.values()), clip) if clip is not None else None
     d_opt.apply(d_sd, grads, lr, beta1, beta2)
     return metrics, grads
 
 
 def g_step(g_sd, d_sd, g_opt: AdamState, z, size, lr=2e-4, beta1=0.5, beta2=0.999,
-           clip: Optional[float] = None, signs=None, record=None):
-    metrics, grads, fp, fake = g_grads(g_sd, d_sd, z, size, signs, record)
+           clip: Optional[float] = None, signs=None, record=None, q=None):
+    metrics, grads, fp, fake = g_grads(g_sd, d_sd, z, size, signs, record, q)
     metrics["g_grad_norm"] = clip_grad_norm(list(grads.values()), clip) if clip is not None else None
     g_opt.apply(g_sd, grads, lr, beta1, beta2)
     return metrics, grads

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be loaded before the library; see module docst
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsiggan_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 M_COUNT = 16
 METRIC_INDEX = {"d_loss": 0, "d_loss_real": 1, "d_loss_fake": 2, "d_real_mean": 3, "d_fake_mean": 4,
                 "d_real_acc": 5, "d_fake_acc": 6, "d_grad_norm": 7, "g_loss": 8, "g_fake_mean": 9,
@@ -21,7 +21,10 @@ METRIC_INDEX = {"d_loss": 0, "d_loss_real": 1, "d_loss_fake": 2, "d_real_mean": 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("latent_dim", C.c_int32), ("image_size", C.c_int32),
                 ("image_channels", C.c_int32), ("max_batch", C.c_int32), ("dropout", C.c_float),
-                ("leaky_slope", C.c_float), ("seed", C.c_uint64)]
+                ("leaky_slope", C.c_float), ("seed", C.c_uint64), ("dtype", C.c_int32), ("f16_grad_scale", C.c_float)]
+
+
+DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
 
 
 class Storage(C.Structure):
@@ -50,6 +53,7 @@ _SIGNATURES = {
     "siggan_bind": (C.c_int, [_P, C.POINTER(Storage)]),
     "siggan_params_changed": (C.c_int, [_P]),
     "siggan_seed": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
+    "siggan_rng_state": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "siggan_set_mode": (C.c_int, [_P, _I32]),
     "siggan_g_forward": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "siggan_d_forward": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P]),

@@ -1,9 +1,12 @@
 // gconv.h -- argument blocks of the MFMA implicit-GEMM kernels (4x4 stride-2 pad-1 family).
-// All activations are NHWC fp32 inside the library; see DESIGN.md "data layout in HBM".
+// All activations are NHWC inside the library, element type `dt` (fp32 by default; bf16 / f16 for the narrow variants,
+// see act.h); see DESIGN.md "data layout in HBM".
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
+
+#include "act.h"
 
 namespace siggan {
 
@@ -16,9 +19,10 @@ enum Epilogue : int {
 
 // out[n, opix, co] = sum_{tap, ci} in[n, pix(tap), ci] * wp[cls][co][tap*Ci + ci]
 struct GConvArgs {
-    const float* in;      // [B][Hi][Wi][Ci]
-    const float* wp;      // packed weights [ncls][Co][ntaps*Ci]
-    float* out;           // [B][Ho][Wo][Co]
+    int dt;               // element type of in / wp / out / aref (DT_F32, DT_BF16, DT_F16)
+    const void* in;       // [B][Hi][Wi][Ci]
+    const void* wp;       // packed weights [ncls][Co][ntaps*Ci]
+    void* out;            // [B][Ho][Wo][Co]
     int B, Hi, Wi, Ci, Co;
     int lgHr, lgWr;       // log2 of the per-image row grid (down: Ho,Wo; up: Hi,Wi)
     int Ho, Wo;
@@ -29,9 +33,9 @@ struct GConvArgs {
     const float* noise;   // [B][Co] dropout multipliers (0 or 1/(1-p)); nullptr = none
     const float* scale;   // [Co]
     const float* shift;   // [Co]
-    const float* aref;    // [B][Ho][Wo][Co] stored activation (EPI_LRELU_BWD)
+    const void* aref;     // [B][Ho][Wo][Co] stored activation (EPI_LRELU_BWD)
     float slope;
-    // split-K scratch (optional): nsplit slabs of the whole output, summed by k_splitk_epilogue
+    // split-K scratch (optional): nsplit fp32 slabs of the whole output, summed by k_splitk_epilogue
     float* slab;
     int64_t slab_floats;
     size_t slab_stride;   // filled by launch_gconv
@@ -40,8 +44,9 @@ struct GConvArgs {
 
 // slab[z][i][tap*Cl + l] = sum_{pix in split z} S[pix][i] * L[n, 2p-1+kh, 2q-1+kw][l]
 struct WgradArgs {
-    const float* S;       // [B][Hs][Ws][Cs]   (small spatial)
-    const float* L;       // [B][2Hs][2Ws][Cl] (large spatial)
+    int dt;               // element type of S and L; slab / dw / db are always fp32
+    const void* S;        // [B][Hs][Ws][Cs]   (small spatial)
+    const void* L;        // [B][2Hs][2Ws][Cl] (large spatial)
     float* slab;          // [nsplit][Cs][16*Cl]
     float* dw;            // result, torch layout: dw[(i*Cl + l)*16 + tap]
     float* db;            // optional: db[i] = sum_pix S[pix][i] (the bias gradient when S is d(pre-activation)); partials
@@ -61,17 +66,16 @@ struct Prof {
     std::vector<Rec> recs;
     static const char* name(int id);
     void begin(int id, double flops, hipStream_t st);
-    void end(hipStream_t st);
     void clear();
 };
 extern Prof* g_prof;
 
 void launch_gconv(const GConvArgs& a, hipStream_t st);
+// 16-bit operand kernels (gconv16.hip); cfg: 0 = 128x128, 2 = 64x64, 3 = 128x32 tiles; e0 / e1: optional timing events
+void launch_gconv16(int cfg, const GConvArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+void launch_wgrad16(bool small, const WgradArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 // fills a.dw (through the slabs + k_wgrad_reduce when K is split); returns the number of K splits
 // (slab must hold max_splits*Cs*(16*Cl + 1) floats)
 int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st);
-// torch layout (O,I,4,4) -> down pack [O][tap*I + i];  torch (I,O,4,4) -> up pack [4][O][t*I + i]
-void launch_pack_down(const float* w, float* wp, int O, int I, hipStream_t st);
-void launch_pack_up(const float* w, float* wp, int I, int O, hipStream_t st);
 
 }  // namespace siggan

@@ -20,8 +20,6 @@
 
 namespace siggan {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int BK = 32;    // K-tile (floats)
 static constexpr int PAD = 4;    // LDS row padding (floats)
@@ -51,6 +49,8 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+    const float* const a_in = static_cast<const float*>(a.in);
+    const float* const a_wp = static_cast<const float*>(a.wp);
 
     const int tiles_n = a.Co / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -77,14 +77,14 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
         if (m < a.M) {
             const int n = m >> (a.lgHr + a.lgWr);
             const int rh = (m >> a.lgWr) & (Hr - 1), rw = m & (Wr - 1);
-            a_base[p] = a.in + (size_t)n * a.Hi * a.Wi * a.Ci + kc * 4;
+            a_base[p] = a_in + (size_t)n * a.Hi * a.Wi * a.Ci + kc * 4;
             if (a.form == 0) { a_ih0[p] = 2 * rh - 1; a_iw0[p] = 2 * rw - 1; }
             else             { a_ih0[p] = rh + ph;    a_iw0[p] = rw + pw; }
         } else {
-            a_base[p] = a.in; a_ih0[p] = -(1 << 20); a_iw0[p] = -(1 << 20);
+            a_base[p] = a_in; a_ih0[p] = -(1 << 20); a_iw0[p] = -(1 << 20);
         }
     }
-    const float* wcur = a.wp + ((size_t)cls * a.Co + n0 + rloc) * Ktot + kc * 4 + (size_t)k_lo * BK;
+    const float* wcur = a_wp + ((size_t)cls * a.Co + n0 + rloc) * Ktot + kc * 4 + (size_t)k_lo * BK;
 
     // load cursor: walks (tap, channel chunk) in K order; per-row source pointers are rebuilt only
     // when the tap changes, otherwise they advance by 32 floats (0 for out-of-image taps, which
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     }
 
     // ---- epilogue ----------------------------------------------------------------------
-    float* const outp = gridDim.y > 1 ? a.slab + (size_t)blockIdx.y * a.slab_stride : a.out;
+    float* const outp = gridDim.y > 1 ? a.slab + (size_t)blockIdx.y * a.slab_stride : static_cast<float*>(a.out);
     const int epi = gridDim.y > 1 ? (int)EPI_RAW : a.epi;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
                 } else if (epi == EPI_AFFINE_RELU) {
                     v = fmaxf(fmaf(v, a.scale[co], a.shift[co]), 0.f);
                 } else if (epi == EPI_LRELU_BWD) {
-                    const float ar = a.aref[o];
+                    const float ar = static_cast<const float*>(a.aref)[o];
                     v *= ar > 0.f ? 1.f : a.slope;
                     if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
                 }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_gconv_up4(const GConvArgs a) {
 
     // ---- the input patch: rows rh0-1 .. rh0+rows, columns -1 .. Wr, every channel ----------------------------
     {
-        const float* const img = a.in + (size_t)n_img * a.Hi * a.Wi * CI;
+        const float* const img = static_cast<const float*>(a.in) + (size_t)n_img * a.Hi * a.Wi * CI;
         const int nchunk = (rows + 2) * Wp * (CI / 4);
         constexpr int NI = (PATCH_PIX * (CI / 4) + 255) / 256;      // loads per thread, all issued before the first LDS write
         f32x4 v[NI];
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void k_gconv_up4(const GConvArgs a) {
     // ---- weight tiles: K-tile kt = (class, channel chunk); its four taps' [32 co][32 ci] tiles are staged together by
     // thread (rloc = output channel, kc = 16-byte chunk), one tile ahead of the MFMAs ----------------------------------
     const int kc = tid & 7, rloc = tid >> 3;
-    const float* const w_row = a.wp + (size_t)rloc * Ktot + kc * 4;
+    const float* const w_row = static_cast<const float*>(a.wp) + (size_t)rloc * Ktot + kc * 4;
     f32x4 rb[4];
     int l_k = 0;
     auto load_tile = [&]() __attribute__((always_inline)) {
@@ -367,13 +367,14 @@ __global__ __launch_bounds__(256) void k_gconv_up4(const GConvArgs a) {
         }
     }
     __syncthreads();
-    f32x4* const dst = reinterpret_cast<f32x4*>(a.out + ((size_t)n_img * a.Ho + 2 * rh0) * a.Wo * BN);
+    f32x4* const dst = reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + ((size_t)n_img * a.Ho + 2 * rh0) * a.Wo * BN);
     const f32x4* const src = reinterpret_cast<const f32x4*>(so);
 #pragma unroll
     for (int q = 0; q < (BM * 4 * BN / 4) / 256; ++q) dst[q * 256 + tid] = src[q * 256 + tid];
 }
 
 // split-K tail: out = epilogue(sum_z slab[z]) over the NHWC output (4 channels per thread)
+template <class T>
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int nsplit, int64_t total4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int 
 #pragma unroll
         for (int k = 0; k < 4; ++k) e[k] = fmaxf(fmaf(e[k], a.scale[c + k], a.shift[c + k]), 0.f);
     } else if (a.epi == EPI_LRELU_BWD) {
-        const float4 ar = reinterpret_cast<const float4*>(a.aref)[i];
+        const f32x4 ar = ld4<T>(static_cast<const T*>(a.aref) + i * 4);
         const float* r = reinterpret_cast<const float*>(&ar);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int 
             e[k] = x;
         }
     }
-    reinterpret_cast<float4*>(a.out)[i] = v;
+    st4<T>(static_cast<T*>(a.out) + i * 4, f32x4{v.x, v.y, v.z, v.w});
 }
 
 Prof* g_prof = nullptr;
@@ -427,7 +428,6 @@ void Prof::begin(int id, double flops, hipStream_t) {
     (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
     recs.push_back(r);
 }
-void Prof::end(hipStream_t) {}
 void Prof::clear() {
     for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     recs.clear();
@@ -439,15 +439,18 @@ static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     const int ncls = a.form == 0 ? 1 : 4;
     dim3 grid(tiles, nsplit, ncls);
     // algorithmic FLOPs = 2 * M * Co * (taps * Ci) per class (== 2 * conv MACs, padding taps included)
-    if (g_prof) {
-        g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, st);
-        hipExtLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT>), grid, dim3(256), 0, st, g_prof->recs.back().e0, g_prof->recs.back().e1, 0, a);
+    if (g_prof) g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, st);
+    hipEvent_t e0 = g_prof ? g_prof->recs.back().e0 : nullptr, e1 = g_prof ? g_prof->recs.back().e1 : nullptr;
+    if (a.dt != DT_F32) {
+        launch_gconv16(id, a, grid, st, e0, e1);
+    } else if (g_prof) {
+        hipExtLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT>), grid, dim3(256), 0, st, e0, e1, 0, a);
     } else {
         hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT>), grid, dim3(256), 0, st, a);
     }
     if (nsplit > 1) {
         const int64_t total4 = (int64_t)a.B * a.Ho * a.Wo * a.Co / 4;
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a, nsplit, total4);
+        SIGGAN_DT_SWITCH(a.dt, T, hipLaunchKernelGGL(k_splitk_epilogue<T>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a, nsplit, total4));
     }
 }
 
@@ -480,7 +483,7 @@ void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         const int ns = splits(blocks(64, 64));
         return launch_cfg<64, 64, 2, 2>(a, st, 2, ns);
     }
-    if (a.form == 1 && a.Co == 32 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU) && (a.Ci == 32 || a.Ci == 64) &&
+    if (a.dt == DT_F32 && a.form == 1 && a.Co == 32 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU) && (a.Ci == 32 || a.Ci == 64) &&
         a.M / 128 >= (a.Ci == 32 ? 384 : 768) && a.M % 128 == 0 &&
         ((1 << (a.lgHr + a.lgWr)) % 128) == 0 && a.lgWr >= 4 && a.lgWr <= 6) {
         // all four parity classes per workgroup, input patch resident in LDS (k_gconv_up4): the short-K Generator blocks
@@ -521,6 +524,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
 
     const int ca = tid % CA, ka = tid / CA;
     const int cb = tid % CB, kb = tid / CB;
+    const float* const a_S = static_cast<const float*>(a.S);
+    const float* const a_L = static_cast<const float*>(a.L);
     const int jj = j0 + cb * 4, tap = jj >> a.lgCl, lch = jj & (Cl - 1);
     const int kh = tap >> 2, kw = tap & 3;
 
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
         const int kbase = kbeg + (KT) * BK;                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                              \
             const int pix = kbase + ka + RA * p;                                                      \
-            const float* src = pix < kend ? a.S + ((size_t)pix * a.Cs + i0 + ca * 4) : a.zeros;       \
+            const float* src = pix < kend ? a_S + ((size_t)pix * a.Cs + i0 + ca * 4) : a.zeros;       \
             ra[p] = *reinterpret_cast<const f32x4*>(src);                                            \
         }                                                                                             \
         _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                              \
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
             const int n = pix >> (a.lgHs + a.lgWs);                                                   \
             const int ih = 2 * ((pix >> a.lgWs) & (Hs - 1)) - 1 + kh, iw = 2 * (pix & (Ws - 1)) - 1 + kw; \
             const bool ok = pix < kend && (unsigned)ih < (unsigned)Hl && (unsigned)iw < (unsigned)Wl; \
-            const float* src = ok ? a.L + ((((size_t)n * Hl + ih) * Wl + iw) * Cl + lch) : a.zeros;   \
+            const float* src = ok ? a_L + ((((size_t)n * Hl + ih) * Wl + iw) * Cl + lch) : a.zeros;   \
             rb[p] = *reinterpret_cast<const f32x4*>(src);                                            \
         }                                                                                             \
     }
@@ -663,7 +668,10 @@ int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
     a.kchunk = per * BK;
     nsplit = (ktiles + per - 1) / per;
     dim3 grid(tiles, 1, nsplit);
-    if (g_prof) {
+    if (a.dt != DT_F32) {
+        if (g_prof) g_prof->begin(small ? 6 : 4, 2.0 * a.Cs * (double)N * a.K, st);
+        launch_wgrad16(small, a, grid, st, g_prof ? g_prof->recs.back().e0 : nullptr, g_prof ? g_prof->recs.back().e1 : nullptr);
+    } else if (g_prof) {
         g_prof->begin(small ? 6 : 4, 2.0 * a.Cs * (double)N * a.K, st);
         hipEvent_t e0 = g_prof->recs.back().e0, e1 = g_prof->recs.back().e1;
         if (small) hipExtLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, e0, e1, 0, a);
@@ -718,49 +726,6 @@ static void launch_wgrad_reduce(const float* slab, float* dw, float* db, int nsp
     while (SL < 16 && SL < nsplit) SL *= 2;
     const unsigned blocks = (unsigned)(total / 64) + (db ? (unsigned)((Cs + 63) / 64) : 0u);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(64 * SL), 0, st, slab, dw, db, nsplit, Cs, ilog2(Cl));
-}
-
-// ------------------------------------------------------------------------------------------
-// weight packing (torch layouts -> GEMM-friendly k-contiguous rows)
-// ------------------------------------------------------------------------------------------
-__global__ void k_pack_down(const float* __restrict__ w, float* __restrict__ wp, int O, int I) {
-    // w[o][i][kh][kw] -> wp[o][(kh*4+kw)*I + i]
-    const size_t total = (size_t)O * I * 16;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(idx % I);
-        const int tap = (int)((idx / I) % 16);
-        const int o = (int)(idx / ((size_t)I * 16));
-        wp[idx] = w[((size_t)o * I + i) * 16 + tap];
-    }
-}
-
-__global__ void k_pack_up(const float* __restrict__ w, float* __restrict__ wp, int I, int O) {
-    // w[i][o][kh][kw] -> wp[cls=(ph,pw)][o][(th*2+tw)*I + i],  kh = 1-ph+2th, kw = 1-pw+2tw
-    const size_t total = (size_t)O * I * 16;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(idx % I);
-        const int t = (int)((idx / I) % 4);
-        const int o = (int)((idx / ((size_t)I * 4)) % O);
-        const int cls = (int)(idx / ((size_t)I * 4 * O));
-        const int ph = cls >> 1, pw = cls & 1, th = t >> 1, tw = t & 1;
-        const int kh = 1 - ph + 2 * th, kw = 1 - pw + 2 * tw;
-        wp[idx] = w[((size_t)i * O + o) * 16 + kh * 4 + kw];
-    }
-}
-
-void launch_pack_down(const float* w, float* wp, int O, int I, hipStream_t st) {
-    const size_t total = (size_t)O * I * 16;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_pack_down, dim3(blocks), dim3(256), 0, st, w, wp, O, I);
-}
-void launch_pack_up(const float* w, float* wp, int I, int O, hipStream_t st) {
-    const size_t total = (size_t)O * I * 16;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_pack_up, dim3(blocks), dim3(256), 0, st, w, wp, I, O);
 }
 
 }  // namespace siggan

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "act.h"
+
 namespace siggan {
 
 // device-resident per-call state: nothing a captured launch needs lives in kernel arguments
@@ -32,6 +34,7 @@ void launch_tick(DevState* st, hipStream_t s);
 enum PrepType : int { PREP_PACK_DOWN = 0, PREP_PACK_UP, PREP_FC_T, PREP_CLS, PREP_BN_EVAL };
 struct PrepJob {
     int type, O, I, perm;        // PACK_*: (O,I) channel counts; FC_T: O=K, I=C0; CLS: O=C; BN_EVAL: O=C, perm=perm_c0
+    int dt;                      // PACK_DOWN / PACK_UP: element type of dst (DT_F32 / DT_BF16 / DT_F16); fp32 for the rest
     const float* src;            // weights (torch layout) / gamma
     const float* src2;           // beta
     const float* src3;           // running_mean
@@ -41,64 +44,69 @@ struct PrepJob {
 struct PrepTable {
     static constexpr int MAXJ = 32;
     int njobs;
+    int overflow;                // set by prep_add when a job did not fit: launch_prepare then fails instead of dropping it
     long long prefix[MAXJ + 1];  // prefix sums of the jobs' element counts
     PrepJob job[MAXJ];
 };
 void prep_add(PrepTable& t, const PrepJob& j, long long count);
-void launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s);
+bool launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s);   // false: the table overflowed (nothing launched)
 
 // ---- Generator pieces ---------------------------------------------------------------------
 // y[n][f'] = z[n,:] . W[f,:] + b[f],  f' = hw*C0 + c  <->  f = c*16 + hw   (NHWC feature order)
-void launch_fc_pack(const float* W, float* Wt, int K, int C0, hipStream_t s);   // Wt[k][f'] = W[f][k]
 // bn_affine_relu != nullptr (eval): y = relu((z.Wt + b) * scale + shift) with [scale | shift] of the folded BatchNorm1d.
 // z == nullptr: z ~ N(0,1) is drawn inside the kernel (the values launch_randn(z_out, B*K, st, stream_id) would write) and
 // also stored to z_out
-void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s,
+// (dt: element type of the activation / gradient tensors passed as void*, see act.h)
+void launch_fc_fwd(int dt, const float* z, const float* Wt, const float* b, void* y, int B, int K, int C0, hipStream_t s,
                    const float* bn_affine_relu = nullptr, const DevState* st = nullptr, uint32_t stream_id = 0,
                    float* z_out = nullptr);
 // dW[f][k] = sum_n dy[n][f'] z[n][k];  db[f] = sum_n dy[n][f']
-void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s);
+void launch_fc_wgrad(int dt, const void* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s);
 
 // training statistics over R rows + running-stat update (momentum, unbiased var) + batches++
-void launch_bn_train_stats(const float* y, int64_t R, int C, const float* gamma, const float* beta,
+void launch_bn_train_stats(int dt, const void* y, int64_t R, int C, const float* gamma, const float* beta,
                            float* rmean, float* rvar, int64_t* batches, float* bn, float* partial,
                            int perm_c0, float momentum, float eps, hipStream_t s);
 // a = relu(y*scale + shift)
-void launch_bn_relu(const float* y, float* a, int64_t R, int C, const float* bn, hipStream_t s);
+void launch_bn_relu(int dt, const void* y, void* a, int64_t R, int C, const float* bn, hipStream_t s);
 // backward through relu(BN(y)): da (in) -> dy (in place); dgamma/dbeta (torch order) written.  The relu mask is
 // re-derived from y and the layer's scale/shift (the forward's own expression), so the activation is not read.
-void launch_bn_bwd(float* da, const float* y, int64_t R, int C, float* bn, float* partial,
+void launch_bn_bwd(int dt, void* da, const void* y, int64_t R, int C, float* bn, float* partial,
                    float* dgamma, float* dbeta, int perm_c0, hipStream_t s);
 
 // final 3x3 conv (C->1) + tanh, and its backward pieces.  act: [B][S][S][C] NHWC, img [B][S][S]
-void launch_final_fwd(const float* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s);
+void launch_final_fwd(int dt, const void* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s);
 // backward of the last Generator block from dpre in one pass family: d(act) of the final conv (recomputed, never stored),
 // relu mask re-derived from y, BatchNorm statistics + apply -> dy; dgamma/dbeta written
-void launch_final_dgrad_bn_bwd(const float* dpre, const float* W, const float* y, float* dy, int B, int S, int C, float* bn,
+void launch_final_dgrad_bn_bwd(int dt, const float* dpre, const float* W, const void* y, void* dy, int B, int S, int C, float* bn,
                                float* partial, float* dgamma, float* dbeta, hipStream_t s);
-void launch_final_wgrad(const float* dpre, const float* act, float* dW, float* db, float* partial, int B, int S,
+void launch_final_wgrad(int dt, const float* dpre, const void* act, float* dW, float* db, float* partial, int B, int S,
                         int C, hipStream_t s);
 
 // ---- Discriminator pieces -----------------------------------------------------------------
 // first block (Cin = 1): x = two segments (x0: n < n0, x1: the rest), out [B][S/2][S/2][C]
-void launch_conv1_fwd(const float* x0, int n0, const float* x1, const float* W, const float* b,
-                      const float* noise, float slope, float* out, int B, int S, int C, hipStream_t s);
-void launch_conv1_wgrad(const float* dv, const float* x0, int n0, const float* x1, float* dW, float* db,
+void launch_conv1_fwd(int dt, const float* x0, int n0, const float* x1, const float* W, const float* b,
+                      const float* noise, float slope, void* out, int B, int S, int C, hipStream_t s);
+void launch_conv1_wgrad(int dt, const void* dv, const float* x0, int n0, const float* x1, float* dW, float* db,
                         float* partial, int B, int S, int C, hipStream_t s);
 // d(image) = conv1 input-gradient, times tanh' = 1 - img^2  ->  dpre
-void launch_conv1_dgrad_tanh(const float* dv, const float* W, const float* img, float* dpre, int B, int S,
+void launch_conv1_dgrad_tanh(int dt, const void* dv, const float* W, const float* img, float* dpre, int B, int S,
                              int C, hipStream_t s);
-void launch_cls_fwd(const float* act, const float* wcp, const float* bc, float* logits, int B, int F, hipStream_t s);
-void launch_cls_features(const float* act, float* feat, int B, int C, hipStream_t s);
+void launch_cls_fwd(int dt, const void* act, const float* wcp, const float* bc, float* logits, int B, int F, hipStream_t s);
+void launch_cls_features(int dt, const void* act, float* feat, int B, int C, hipStream_t s);
 // sigmoid + BCE (mean per segment) + d(logit); seg0 = first n0 rows with target y0, rest target y1
+// gscale: d(logit) is multiplied by it (the fp16 gradient scale; every gradient downstream then carries it and the optimiser
+// step divides it out again -- 1 for fp32 / bf16)
 void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* probs, float* dlogit,
-                float* metrics, int is_g_step, hipStream_t s);
+                float* metrics, int is_g_step, hipStream_t s, float gscale = 1.0f);
 // dv[n][hw][c] = dlogit[n] * wcp[hw*C+c] * leaky'(act) * noise[n][c]
 // from the logits (rows < n0: target y0, the rest y1; each segment's mean): d(logit) is recomputed with k_bce's expression
-void launch_cls_bwd(const float* logits, int n0, float y0, float y1, const float* wcp, const float* act, const float* noise,
-                    float slope, float* dv, int B, int C, hipStream_t s);
+void launch_cls_bwd(int dt, const float* logits, int n0, float y0, float y1, const float* wcp, const void* act, const float* noise,
+                    float slope, void* dv, int B, int C, hipStream_t s, float gscale = 1.0f);
 // dWc (torch order c*16+hw) and dbc
-void launch_cls_wgrad(const float* dlogit, const float* act, float* dWc, float* dbc, int B, int C, hipStream_t s);
+void launch_cls_wgrad(int dt, const float* dlogit, const void* act, float* dWc, float* dbc, int B, int C, hipStream_t s);
+// dst[i] = (float)src[i] for a tensor of element type dt
+void launch_to_f32(int dt, const void* src, float* dst, int64_t n, hipStream_t s);
 
 // ---- optimiser ------------------------------------------------------------------------------
 // reads steps[0], writes steps[i] += 1 for every tensor, derives the Adam scalars; with

@@ -93,11 +93,17 @@ static long long prep_units(const PrepJob& j) {
     }
 }
 void prep_add(PrepTable& t, const PrepJob& j, long long /*count*/) {
-    if (t.njobs >= PrepTable::MAXJ) return;
+    if (t.njobs >= PrepTable::MAXJ) { t.overflow = 1; return; }   // launch_prepare refuses an incomplete table
     if (t.njobs == 0) t.prefix[0] = 0;
     t.job[t.njobs] = j;
     t.prefix[t.njobs + 1] = t.prefix[t.njobs] + prep_units(j);
     ++t.njobs;
+}
+// a packed weight goes out in the element type the consuming kernel reads (q.dt: fp32, or bf16 / f16 rounded to nearest)
+__device__ __forceinline__ void put_w(const PrepJob& q, size_t idx, float v) {
+    if (q.dt == DT_F32) q.dst[idx] = v;
+    else if (q.dt == DT_BF16) reinterpret_cast<bf16_t*>(q.dst)[idx] = (bf16_t)v;
+    else reinterpret_cast<f16_t*>(q.dst)[idx] = (f16_t)v;
 }
 __global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
     extern __shared__ float tile[];
@@ -111,8 +117,8 @@ __global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
         const float* src = q.src + (size_t)u * I * 16;
         for (int e = tid; e < I * 16; e += 256) tile[(e >> 4) * 17 + (e & 15)] = src[e];
         __syncthreads();
-        float* dst = q.dst + (size_t)u * I * 16;
-        for (int e = tid; e < I * 16; e += 256) { const int tap = e / I, i = e - tap * I; dst[e] = tile[i * 17 + tap]; }
+        const size_t d0 = (size_t)u * I * 16;
+        for (int e = tid; e < I * 16; e += 256) { const int tap = e / I, i = e - tap * I; put_w(q, d0 + e, tile[i * 17 + tap]); }
     } else if (q.type == PREP_PACK_UP) {
         const int I = q.I, O = q.O;
         for (int e = tid; e < I * 16; e += 256) tile[(e >> 4) * 17 + (e & 15)] = q.src[((size_t)(e >> 4) * O + u) * 16 + (e & 15)];
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
         for (int e = tid; e < I * 16; e += 256) {
             const int i = e % I, tt = (e / I) & 3, cls = e / (4 * I);
             const int kh = 1 - (cls >> 1) + 2 * (tt >> 1), kw = 1 - (cls & 1) + 2 * (tt & 1);
-            q.dst[((size_t)cls * O + u) * 4 * I + tt * I + i] = tile[i * 17 + kh * 4 + kw];
+            put_w(q, ((size_t)cls * O + u) * 4 * I + tt * I + i, tile[i * 17 + kh * 4 + kw]);
         }
     } else if (q.type == PREP_FC_T) {            // K = q.O, C0 = q.I
         const int K = q.O, C0 = q.I, F = C0 * 16, kchunks = (K + 127) / 128;
@@ -141,10 +147,12 @@ __global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
         }
     }
 }
-void launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s) {
-    if (t.njobs == 0) return;
+bool launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s) {
+    if (t.overflow) return false;
+    if (t.njobs == 0) return true;
     // LDS: 512 input channels x 17 floats (conv packs) or 64 x 129 (fc) -- 34.8 KB
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)t.prefix[t.njobs]), dim3(256), 512 * 17 * sizeof(float), s, t, bn_eps);
+    return true;
 }
 
 // =========================================================================================
@@ -216,20 +224,23 @@ __device__ __forceinline__ void gather2(const float* __restrict__ p0, const floa
     for (int k = 0; k < nl; ++k) { s += s0[k * W + cl]; q += s1[k * W + cl]; }
 }
 
+__device__ __forceinline__ float4 f4(const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
+template <class T>
 struct FStats {   // shifted sums around the first row: robust single-pass variance
-    const float4* y;
+    const T* y;
     __device__ void operator()(int64_t r, int c4, int C4, float4& s0, float4& s1) const {
-        const float4 v = y[r * C4 + c4], p = y[c4];
+        const float4 v = f4(ld4<T>(y + (r * C4 + c4) * 4)), p = f4(ld4<T>(y + c4 * 4));
         const float4 d = make_float4(v.x - p.x, v.y - p.y, v.z - p.z, v.w - p.w);
         add4(s0, d);
         s1.x = fmaf(d.x, d.x, s1.x); s1.y = fmaf(d.y, d.y, s1.y); s1.z = fmaf(d.z, d.z, s1.z); s1.w = fmaf(d.w, d.w, s1.w);
     }
 };
+template <class T>
 struct FBnBwd {   // relu mask re-derived from y (a > 0 <=> fma(y, scale, shift) > 0, k_bn_relu's own expression): a is not read
-    const float4* da; const float4* y; const float4* bn;
+    const T* da; const T* y; const float4* bn;
     __device__ void operator()(int64_t r, int c4, int C4, float4& s0, float4& s1) const {
         const size_t i = (size_t)r * C4 + c4;
-        const float4 g = da[i], yy = y[i], sc = bn[c4], sf = bn[C4 + c4], mu = bn[2 * C4 + c4], rs = bn[3 * C4 + c4];
+        const float4 g = f4(ld4<T>(da + i * 4)), yy = f4(ld4<T>(y + i * 4)), sc = bn[c4], sf = bn[C4 + c4], mu = bn[2 * C4 + c4], rs = bn[3 * C4 + c4];
         const float4 d = make_float4(fmaf(yy.x, sc.x, sf.x) > 0.f ? g.x : 0.f, fmaf(yy.y, sc.y, sf.y) > 0.f ? g.y : 0.f,
                                      fmaf(yy.z, sc.z, sf.z) > 0.f ? g.z : 0.f, fmaf(yy.w, sc.w, sf.w) > 0.f ? g.w : 0.f);
         add4(s0, d);
@@ -242,9 +253,9 @@ struct FBnBwd {   // relu mask re-derived from y (a > 0 <=> fma(y, scale, shift)
 // =========================================================================================
 // BatchNorm
 // =========================================================================================
-template <int W>
+template <int W, class T>
 __global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
-                               const float* __restrict__ y, const float* __restrict__ gamma,
+                               const T* __restrict__ y, const float* __restrict__ gamma,
                                const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                int64_t* __restrict__ batches, float* __restrict__ bn, int perm_c0, float momentum,
                                float eps) {
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__
     if (threadIdx.x >= W || c >= C) return;
     const float invR = 1.0f / (float)R;
     const float d = s * invR;
-    const float mean = y[c] + d;
+    const float mean = ld1<T>(y + c) + d;
     float var = q * invR - d * d;
     var = var > 0.f ? var : 0.f;
     const float rstd = 1.0f / sqrtf(var + eps);
@@ -267,33 +278,37 @@ __global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__
     rmean[t] = momentum * mean + (1.0f - momentum) * rmean[t];
     rvar[t] = momentum * unb + (1.0f - momentum) * rvar[t];
 }
-void launch_bn_train_stats(const float* y, int64_t R, int C, const float* gamma, const float* beta, float* rmean,
+void launch_bn_train_stats(int dt, const void* yv, int64_t R, int C, const float* gamma, const float* beta, float* rmean,
                            float* rvar, int64_t* batches, float* bn, float* partial, int perm_c0, float momentum,
                            float eps, hipStream_t s) {
     const ColPlan pl = col_plan(R, C);
     float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
-    hipLaunchKernelGGL((k_colreduce<FStats>), dim3(pl.cbx, pl.nch), dim3(256), 0, s, FStats{(const float4*)y}, R, C, pl.cg, pl.rows, p0, p1);
-    if (C <= 32)
-        hipLaunchKernelGGL(k_bn_train_fin<32>, dim3(cdiv(C, 32)), dim3(1024), 0, s, p0, p1, pl.nch, R, C, y, gamma, beta, rmean,
-                           rvar, batches, bn, perm_c0, momentum, eps);
-    else
-        hipLaunchKernelGGL(k_bn_train_fin<64>, dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, p1, pl.nch, R, C, y, gamma, beta, rmean,
-                           rvar, batches, bn, perm_c0, momentum, eps);
+    SIGGAN_DT_SWITCH(dt, T, {
+        const T* y = (const T*)yv;
+        hipLaunchKernelGGL((k_colreduce<FStats<T>>), dim3(pl.cbx, pl.nch), dim3(256), 0, s, FStats<T>{y}, R, C, pl.cg, pl.rows, p0, p1);
+        if (C <= 32)
+            hipLaunchKernelGGL((k_bn_train_fin<32, T>), dim3(cdiv(C, 32)), dim3(1024), 0, s, p0, p1, pl.nch, R, C, y, gamma, beta, rmean,
+                               rvar, batches, bn, perm_c0, momentum, eps);
+        else
+            hipLaunchKernelGGL((k_bn_train_fin<64, T>), dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, p1, pl.nch, R, C, y, gamma, beta, rmean,
+                               rvar, batches, bn, perm_c0, momentum, eps);
+    });
 }
 
-__global__ void k_bn_relu(const float4* __restrict__ y, float4* __restrict__ a, int64_t n4, int C4,
+template <class T>
+__global__ void k_bn_relu(const T* __restrict__ y, T* __restrict__ a, int64_t n4, int C4,
                           const float4* __restrict__ bn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const int c = (int)(i % C4);
-    const float4 v = y[i], sc = bn[c], sh = bn[C4 + c];
-    a[i] = make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f),
-                       fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+    const float4 v = f4(ld4<T>(y + i * 4)), sc = bn[c], sh = bn[C4 + c];
+    st4<T>(a + i * 4, f32x4{fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f),
+                            fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), fmaxf(fmaf(v.w, sc.w, sh.w), 0.f)});
 }
-void launch_bn_relu(const float* y, float* a, int64_t R, int C, const float* bn, hipStream_t s) {
+void launch_bn_relu(int dt, const void* y, void* a, int64_t R, int C, const float* bn, hipStream_t s) {
     const int64_t n4 = R * C / 4;
-    hipLaunchKernelGGL(k_bn_relu, dim3(cdiv(n4, 256)), dim3(256), 0, s, (const float4*)y, (float4*)a, n4, C / 4,
-                       (const float4*)bn);
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_bn_relu<T>, dim3(cdiv(n4, 256)), dim3(256), 0, s, (const T*)y, (T*)a, n4, C / 4,
+                                                (const float4*)bn));
 }
 
 template <int W>
@@ -314,30 +329,33 @@ static void launch_bn_bwd_fin(const float* p0, const float* p1, int nch, int64_t
     if (C <= 32) hipLaunchKernelGGL(k_bn_bwd_fin<32>, dim3(cdiv(C, 32)), dim3(1024), 0, s, p0, p1, nch, R, C, bn, dgamma, dbeta, perm_c0);
     else hipLaunchKernelGGL(k_bn_bwd_fin<64>, dim3(cdiv(C, 64)), dim3(1024), 0, s, p0, p1, nch, R, C, bn, dgamma, dbeta, perm_c0);
 }
-__global__ void k_bn_bwd_apply(float4* __restrict__ da, const float4* __restrict__ y, int64_t n4, int C4,
+template <class T>
+__global__ void k_bn_bwd_apply(T* __restrict__ da, const T* __restrict__ y, int64_t n4, int C4,
                                const float4* __restrict__ bn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const int c = (int)(i % C4);
-    const float4 g = da[i], yy = y[i];
+    const float4 g = f4(ld4<T>(da + i * 4)), yy = f4(ld4<T>(y + i * 4));
     const float4 sc = bn[c], sf = bn[C4 + c], mu = bn[2 * C4 + c], rs = bn[3 * C4 + c], c1 = bn[4 * C4 + c], c2 = bn[5 * C4 + c];
     float4 o;
     o.x = sc.x * ((fmaf(yy.x, sc.x, sf.x) > 0.f ? g.x : 0.f) - c1.x - (yy.x - mu.x) * rs.x * c2.x);
     o.y = sc.y * ((fmaf(yy.y, sc.y, sf.y) > 0.f ? g.y : 0.f) - c1.y - (yy.y - mu.y) * rs.y * c2.y);
     o.z = sc.z * ((fmaf(yy.z, sc.z, sf.z) > 0.f ? g.z : 0.f) - c1.z - (yy.z - mu.z) * rs.z * c2.z);
     o.w = sc.w * ((fmaf(yy.w, sc.w, sf.w) > 0.f ? g.w : 0.f) - c1.w - (yy.w - mu.w) * rs.w * c2.w);
-    da[i] = o;
+    st4<T>(da + i * 4, f32x4{o.x, o.y, o.z, o.w});
 }
-void launch_bn_bwd(float* da, const float* y, int64_t R, int C, float* bn, float* partial,
+void launch_bn_bwd(int dt, void* dav, const void* yv, int64_t R, int C, float* bn, float* partial,
                    float* dgamma, float* dbeta, int perm_c0, hipStream_t s) {
     const ColPlan pl = col_plan(R, C);
     float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
-    hipLaunchKernelGGL((k_colreduce<FBnBwd>), dim3(pl.cbx, pl.nch), dim3(256), 0, s,
-                       FBnBwd{(const float4*)da, (const float4*)y, (const float4*)bn}, R, C, pl.cg, pl.rows, p0, p1);
-    launch_bn_bwd_fin(p0, p1, pl.nch, R, C, bn, dgamma, dbeta, perm_c0, s);
     const int64_t n4 = R * C / 4;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, s, (float4*)da, (const float4*)y, n4, C / 4,
-                       (const float4*)bn);
+    SIGGAN_DT_SWITCH(dt, T, {
+        T* da = (T*)dav; const T* y = (const T*)yv;
+        hipLaunchKernelGGL((k_colreduce<FBnBwd<T>>), dim3(pl.cbx, pl.nch), dim3(256), 0, s,
+                           FBnBwd<T>{da, y, (const float4*)bn}, R, C, pl.cg, pl.rows, p0, p1);
+        launch_bn_bwd_fin(p0, p1, pl.nch, R, C, bn, dgamma, dbeta, perm_c0, s);
+        hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(cdiv(n4, 256)), dim3(256), 0, s, da, y, n4, C / 4, (const float4*)bn);
+    });
 }
 
 // =========================================================================================
@@ -345,8 +363,9 @@ void launch_bn_bwd(float* da, const float* y, int64_t R, int C, float* bn, float
 // =========================================================================================
 // (Wt[k][f'] = W[f][k] is the k-major copy k_prepare keeps in the NHWC feature order, so lanes walk f' coalesced)
 // one thread = one feature f' x 8 batch rows; z rows broadcast from LDS; 50 weight loads in flight
+template <class T>
 __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, const float* __restrict__ Wt,
-                                                const float* __restrict__ b, float* __restrict__ y, int B, int K, int C0,
+                                                const float* __restrict__ b, T* __restrict__ y, int B, int K, int C0,
                                                 const float* __restrict__ bn, const DevState* __restrict__ st, uint32_t sid,
                                                 float* __restrict__ z_out) {
     extern __shared__ float sz[];   // [8][K]
@@ -414,23 +433,24 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, con
         const float sc = bn[fp], sf = bn[F + fp];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (nb + j < B) y[(size_t)(nb + j) * F + fp] = fmaxf(fmaf(acc[j] + bias, sc, sf), 0.f);
+            if (nb + j < B) st1<T>(y + (size_t)(nb + j) * F + fp, fmaxf(fmaf(acc[j] + bias, sc, sf), 0.f));
         return;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        if (nb + j < B) y[(size_t)(nb + j) * F + fp] = acc[j] + bias;
+        if (nb + j < B) st1<T>(y + (size_t)(nb + j) * F + fp, acc[j] + bias);
 }
-void launch_fc_fwd(const float* z, const float* Wt, const float* b, float* y, int B, int K, int C0, hipStream_t s,
+void launch_fc_fwd(int dt, const float* z, const float* Wt, const float* b, void* y, int B, int K, int C0, hipStream_t s,
                    const float* bn_affine_relu, const DevState* st, uint32_t stream_id, float* z_out) {
-    hipLaunchKernelGGL(k_fc_fwd, dim3(cdiv(C0 * 16, 256), cdiv(B, 8)), dim3(256), 8 * K * sizeof(float), s, z, Wt, b, y, B, K, C0,
-                       bn_affine_relu, st, stream_id, z_out);
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_fc_fwd<T>, dim3(cdiv(C0 * 16, 256), cdiv(B, 8)), dim3(256), 8 * K * sizeof(float), s, z, Wt,
+                                                b, (T*)y, B, K, C0, bn_affine_relu, st, stream_id, z_out));
 }
 // dW[f][k] = sum_n dy[n][f'] * z[n][k],  db[f] = sum_n dy[n][f'].  A thread owns feature f' and a group of
 // FK latent columns: every dy value it loads feeds FK FMAs (z rows broadcast from LDS, 64 batch rows per
 // pass), instead of one load per FMA.
 static constexpr int FK = 8;
-__global__ __launch_bounds__(256) void k_fc_wgrad(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dW,
+template <class T>
+__global__ __launch_bounds__(256) void k_fc_wgrad(const T* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dW,
                            float* __restrict__ db, int B, int K, int C0) {
     __shared__ float sz[64][FK];
     const int F = C0 * 16;
@@ -451,7 +471,7 @@ __global__ __launch_bounds__(256) void k_fc_wgrad(const float* __restrict__ dy, 
             for (; n + 8 <= nn; n += 8) {
                 float g[8];
 #pragma unroll
-                for (int v = 0; v < 8; ++v) g[v] = dy[(size_t)(n0 + n + v) * F + fp];
+                for (int v = 0; v < 8; ++v) g[v] = ld1<T>(dy + (size_t)(n0 + n + v) * F + fp);
 #pragma unroll
                 for (int v = 0; v < 8; ++v) {
                     sb += g[v];
@@ -460,7 +480,7 @@ __global__ __launch_bounds__(256) void k_fc_wgrad(const float* __restrict__ dy, 
                 }
             }
             for (; n < nn; ++n) {
-                const float g = dy[(size_t)(n0 + n) * F + fp];
+                const float g = ld1<T>(dy + (size_t)(n0 + n) * F + fp);
                 sb += g;
 #pragma unroll
                 for (int u = 0; u < FK; ++u) acc[u] = fmaf(g, sz[n][u], acc[u]);
@@ -474,8 +494,9 @@ __global__ __launch_bounds__(256) void k_fc_wgrad(const float* __restrict__ dy, 
         if (k0 + u < K) dW[(size_t)f * K + k0 + u] = acc[u];
     if (blockIdx.y == 0) db[f] = sb;
 }
-void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s) {
-    hipLaunchKernelGGL(k_fc_wgrad, dim3(cdiv(C0 * 16, 256), cdiv(K, FK)), dim3(256), 0, s, dy, z, dW, db, B, K, C0);
+void launch_fc_wgrad(int dt, const void* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s) {
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_fc_wgrad<T>, dim3(cdiv(C0 * 16, 256), cdiv(K, FK)), dim3(256), 0, s, (const T*)dy, z, dW, db,
+                                                B, K, C0));
 }
 
 // =========================================================================================
@@ -485,7 +506,7 @@ void launch_fc_wgrad(const float* dy, const float* z, float* dW, float* db, int 
 // row; a block owns an RY-row strip of one image and reads the (RY+2) x 3 neighbourhood it needs
 // with unconditional loads (clamped address, value selected to 0 outside the image), so every load
 // of the strip is in flight at once.
-typedef float f4v __attribute__((ext_vector_type(4)));
+typedef f32x4 f4v;
 __device__ __forceinline__ f4v ldg4(const float* p) { return *reinterpret_cast<const f4v*>(p); }
 __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
@@ -499,7 +520,8 @@ __device__ __forceinline__ StripId strip_of(int sid, int S, int xi) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ act, const float* __restrict__ W,
+template <class T>
+__global__ __launch_bounds__(256) void k_final_fwd(const T* __restrict__ act, const float* __restrict__ W,
                                                    const float* __restrict__ b, float* __restrict__ img, int S) {
     constexpr int RY = 4, C = 32;
     const int c4 = threadIdx.x & 7;
@@ -511,7 +533,7 @@ __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ act
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f4v*>(sw9 + k * 36 + c4 * 4);
     const float bias = b[0];
-    const float* base = act + (size_t)t.n * S * S * C + c4 * 4;
+    const T* base = act + (size_t)t.n * S * S * C + c4 * 4;
     f4v v[RY + 2][3];
 #pragma unroll
     for (int r = 0; r < RY + 2; ++r) {
@@ -519,7 +541,7 @@ __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ act
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int xx = t.x + d - 1, xc = clampi(xx, S - 1);
-            const f4v q = ldg4(base + ((size_t)yc * S + xc) * C);
+            const f4v q = ld4<T>(base + ((size_t)yc * S + xc) * C);
             v[r][d] = (yy == yc && xx == xc) ? q : f4v{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -537,9 +559,9 @@ __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ act
         if (c4 == 0) img[((size_t)t.n * S + t.y0 + r) * S + t.x] = tanhf(acc + bias);
     }
 }
-void launch_final_fwd(const float* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s) {
+void launch_final_fwd(int dt, const void* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s) {
     (void)C;                                            // host checks C == 32, S % 32 == 0
-    hipLaunchKernelGGL(k_final_fwd, dim3(B * (S / 4) * (S / 32)), dim3(256), 0, s, act, W, b, img, S);
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_fwd<T>, dim3(B * (S / 4) * (S / 32)), dim3(256), 0, s, (const T*)act, W, b, img, S));
 }
 
 // d(act)[y][x][c] = sum_{kh,kw} dpre[y + 1 - kh][x + 1 - kw] * W[c][kh][kw], for the 4 channels of a lane.
@@ -577,8 +599,9 @@ __device__ __forceinline__ f4v final_dact(const float (&d)[RY + 2][3], const f4v
 // Backward through [final conv] <- relu <- BatchNorm of the last Generator block, stage 1: per-channel
 // sums of dy_relu and dy_relu * xhat (the relu mask is re-derived from y: a > 0 <=> fma(y, scale, shift) > 0,
 // the forward's own expression).  One partial row per block; k_bn_bwd_fin adds the rows.
+template <class T>
 __global__ __launch_bounds__(256) void k_final_bnbwd_reduce(const float* __restrict__ dpre, const float* __restrict__ W,
-                                                            const float* __restrict__ y, const float* __restrict__ bn,
+                                                            const T* __restrict__ y, const float* __restrict__ bn,
                                                             float* __restrict__ p0, float* __restrict__ p1, int S, int nstrips) {
     constexpr int RY = 8, C = 32;
     __shared__ f4v sh[2][4][8];
@@ -595,10 +618,10 @@ __global__ __launch_bounds__(256) void k_final_bnbwd_reduce(const float* __restr
         const StripId t = strip_of<RY>(sid, S, threadIdx.x >> 3);
         float d[RY + 2][3];
         load_dpre_strip<RY>(dpre, t, S, d);
-        const float* ybase = y + (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
+        const T* ybase = y + (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
         f4v yv[RY];
 #pragma unroll
-        for (int r = 0; r < RY; ++r) yv[r] = ldg4(ybase + (size_t)r * S * C);
+        for (int r = 0; r < RY; ++r) yv[r] = ld4<T>(ybase + (size_t)r * S * C);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             const f4v g = final_dact<RY>(d, w, r);
@@ -625,9 +648,10 @@ __global__ __launch_bounds__(256) void k_final_bnbwd_reduce(const float* __restr
     }
 }
 // stage 2 (after k_bn_bwd_fin): dy = scale * (dy_relu - c1 - xhat * c2), written to dy[B][S][S][C]
+template <class T>
 __global__ __launch_bounds__(256) void k_final_bnbwd_apply(const float* __restrict__ dpre, const float* __restrict__ W,
-                                                           const float* __restrict__ y, const float* __restrict__ bn,
-                                                           float* __restrict__ dy, int S) {
+                                                           const T* __restrict__ y, const float* __restrict__ bn,
+                                                           T* __restrict__ dy, int S) {
     constexpr int RY = 4, C = 32;
     const int c4 = threadIdx.x & 7;
     const StripId t = strip_of<RY>(blockIdx.x, S, threadIdx.x >> 3);
@@ -644,7 +668,7 @@ __global__ __launch_bounds__(256) void k_final_bnbwd_apply(const float* __restri
     const size_t o0 = (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
     f4v yv[RY];
 #pragma unroll
-    for (int r = 0; r < RY; ++r) yv[r] = ldg4(y + o0 + (size_t)r * S * C);
+    for (int r = 0; r < RY; ++r) yv[r] = ld4<T>(y + o0 + (size_t)r * S * C);
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
         const f4v g = final_dact<RY>(d, w, r);
@@ -654,24 +678,27 @@ __global__ __launch_bounds__(256) void k_final_bnbwd_apply(const float* __restri
         o.y = sc.y * ((fmaf(v.y, sc.y, sf.y) > 0.f ? g.y : 0.f) - c1.y - (v.y - mu.y) * rs.y * c2.y);
         o.z = sc.z * ((fmaf(v.z, sc.z, sf.z) > 0.f ? g.z : 0.f) - c1.z - (v.z - mu.z) * rs.z * c2.z);
         o.w = sc.w * ((fmaf(v.w, sc.w, sf.w) > 0.f ? g.w : 0.f) - c1.w - (v.w - mu.w) * rs.w * c2.w);
-        *reinterpret_cast<f4v*>(dy + o0 + (size_t)r * S * C) = o;
+        st4<T>(dy + o0 + (size_t)r * S * C, o);
     }
 }
-void launch_final_dgrad_bn_bwd(const float* dpre, const float* W, const float* y, float* dy, int B, int S, int C, float* bn,
+void launch_final_dgrad_bn_bwd(int dt, const float* dpre, const float* W, const void* y, void* dy, int B, int S, int C, float* bn,
                                float* partial, float* dgamma, float* dbeta, hipStream_t s) {
     const int nstrips = B * (S / 4) * (S / 32), nstrips8 = nstrips / 2;          // apply: 4-row strips, reduce: 8-row strips
     const int nch = nstrips8 < 1024 ? nstrips8 : 1024;
     float* p0 = partial; float* p1 = partial + (size_t)nch * C;
-    hipLaunchKernelGGL(k_final_bnbwd_reduce, dim3(nch), dim3(256), 0, s, dpre, W, y, bn, p0, p1, S, nstrips8);
-    launch_bn_bwd_fin(p0, p1, nch, (int64_t)B * S * S, C, bn, dgamma, dbeta, 0, s);
-    hipLaunchKernelGGL(k_final_bnbwd_apply, dim3(nstrips), dim3(256), 0, s, dpre, W, y, bn, dy, S);
+    SIGGAN_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL(k_final_bnbwd_reduce<T>, dim3(nch), dim3(256), 0, s, dpre, W, (const T*)y, bn, p0, p1, S, nstrips8);
+        launch_bn_bwd_fin(p0, p1, nch, (int64_t)B * S * S, C, bn, dgamma, dbeta, 0, s);
+        hipLaunchKernelGGL(k_final_bnbwd_apply<T>, dim3(nstrips), dim3(256), 0, s, dpre, W, (const T*)y, bn, (T*)dy, S);
+    });
 }
 
 // dW[c][kh][kw] = sum act[n][y][x][c] * dpre[n][y - kh + 1][x - kw + 1];  db = sum dpre.
 // Each block walks strips (grid-stride), keeps 9 x 4 weight sums + the bias sum per thread, folds the
 // 32 pixel lanes (shuffles inside a wave, LDS across the 4 waves, fixed order) and writes one
 // partial row [C*9 + 1]; k_rows_sum adds the rows.
-__global__ __launch_bounds__(256) void k_final_wgrad(const float* __restrict__ dpre, const float* __restrict__ act,
+template <class T>
+__global__ __launch_bounds__(256) void k_final_wgrad(const float* __restrict__ dpre, const T* __restrict__ act,
                                                      float* __restrict__ partial, int S, int nstrips) {
     constexpr int RY = 8, C = 32;
     __shared__ float sh[4][8][37];
@@ -683,7 +710,7 @@ __global__ __launch_bounds__(256) void k_final_wgrad(const float* __restrict__ d
     for (int sid = blockIdx.x; sid < nstrips; sid += gridDim.x) {
         const StripId t = strip_of<RY>(sid, S, threadIdx.x >> 3);
         const float* dbase = dpre + (size_t)t.n * S * S;
-        const float* abase = act + (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
+        const T* abase = act + (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
         float d[RY + 2][3];
 #pragma unroll
         for (int r = 0; r < RY + 2; ++r) {
@@ -697,7 +724,7 @@ __global__ __launch_bounds__(256) void k_final_wgrad(const float* __restrict__ d
         }
         f4v a[RY];
 #pragma unroll
-        for (int r = 0; r < RY; ++r) a[r] = ldg4(abase + (size_t)r * S * C);
+        for (int r = 0; r < RY; ++r) a[r] = ld4<T>(abase + (size_t)r * S * C);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             sdb += d[r + 1][1];
@@ -745,11 +772,11 @@ __global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ par
     if (threadIdx.x >= 64 || j >= width) return;
     if (j < n0) o0[j] = s; else o1[j - n0] = s;
 }
-void launch_final_wgrad(const float* dpre, const float* act, float* dW, float* db, float* partial, int B, int S, int C,
+void launch_final_wgrad(int dt, const float* dpre, const void* act, float* dW, float* db, float* partial, int B, int S, int C,
                         hipStream_t s) {
     const int nstrips = B * (S / 8) * (S / 32);
     const int nch = nstrips < 1024 ? nstrips : 1024;
-    hipLaunchKernelGGL(k_final_wgrad, dim3(nch), dim3(256), 0, s, dpre, act, partial, S, nstrips);
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_wgrad<T>, dim3(nch), dim3(256), 0, s, dpre, (const T*)act, partial, S, nstrips));
     hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 64)), dim3(1024), 0, s, partial, nch, C * 9 + 1, dW, C * 9, db);
 }
 
@@ -772,10 +799,11 @@ __device__ __forceinline__ void stage_x(float* sx, const float* xp, int oh0, int
 // thread = 4 output channels (16 taps x 4 weights in registers); 16 channel lanes x 16 pixel lanes;
 // a block produces RY output rows of one image from an LDS copy of the input rows (broadcast reads)
 // and writes 256 contiguous bytes per pixel.
+template <class T>
 __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x0, int n0, const float* __restrict__ x1,
                                                    const float* __restrict__ W, const float* __restrict__ b,
                                                    const float* __restrict__ noise, float slope,
-                                                   float* __restrict__ out, int S) {
+                                                   T* __restrict__ out, int S) {
     constexpr int RY = 2, C = 64;
     __shared__ float sx[(2 * RY + 2) * 130];
     __shared__ __attribute__((aligned(16))) float sw[16 * (C + 4)];  // weights transposed to [tap][co] (row stride C + 4: conflict-free both ways)
@@ -807,19 +835,20 @@ __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x0,
         acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
         acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
         if (noise) { acc.x *= nz.x; acc.y *= nz.y; acc.z *= nz.z; acc.w *= nz.w; }
-        *reinterpret_cast<f4v*>(out + (((size_t)n * Ho + oh0 + r) * Ho + ow) * C + q * 4) = acc;
+        st4<T>(out + (((size_t)n * Ho + oh0 + r) * Ho + ow) * C + q * 4, acc);
     }
 }
-void launch_conv1_fwd(const float* x0, int n0, const float* x1, const float* W, const float* b, const float* noise,
-                      float slope, float* out, int B, int S, int C, hipStream_t s) {
+void launch_conv1_fwd(int dt, const float* x0, int n0, const float* x1, const float* W, const float* b, const float* noise,
+                      float slope, void* out, int B, int S, int C, hipStream_t s) {
     (void)C;                                            // host checks C == 64, S in {64, 128}
-    hipLaunchKernelGGL(k_conv1_fwd, dim3(B * (S / 4)), dim3(256), 0, s, x0, n0, x1, W, b, noise, slope, out, S);
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_conv1_fwd<T>, dim3(B * (S / 4)), dim3(256), 0, s, x0, n0, x1, W, b, noise, slope, (T*)out, S));
 }
 
 // dW[co][kh][kw] = sum dv[n][oh][ow][co] * x[n][2oh-1+kh][2ow-1+kw];  db[co] = sum dv.
 // Same thread map as the forward; 17 x 4 sums per thread, folded over the 16 pixel lanes at the end
 // (shuffles, then LDS across the waves); partial row = [C*16 weights (co*16 + tap)] [C biases].
-__global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ dv, const float* __restrict__ x0, int n0,
+template <class T>
+__global__ __launch_bounds__(256) void k_conv1_wgrad(const T* __restrict__ dv, const float* __restrict__ x0, int n0,
                                                      const float* __restrict__ x1, float* __restrict__ partial, int S,
                                                      int nstrips) {
     constexpr int RY = 8, C = 64;
@@ -835,11 +864,11 @@ __global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ d
         __syncthreads();
         stage_x<RY>(sx, seg_ptr(x0, n0, x1, n, S), oh0, S);
         __syncthreads();
-        const float* gbase = dv + ((size_t)n * Ho + oh0) * Ho * C + q * 4;
+        const T* gbase = dv + ((size_t)n * Ho + oh0) * Ho * C + q * 4;
         for (int p0 = pl; p0 < RY * Ho; p0 += 64) {
             f4v g[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) g[u] = ldg4(gbase + (size_t)(p0 + 16 * u) * C);
+            for (int u = 0; u < 4; ++u) g[u] = ld4<T>(gbase + (size_t)(p0 + 16 * u) * C);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = p0 + 16 * u, r = p / Ho, ow = p - r * Ho;
@@ -879,11 +908,11 @@ __global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ d
         out[o] = ((sh[0][g][j] + sh[1][g][j]) + sh[2][g][j]) + sh[3][g][j];
     }
 }
-void launch_conv1_wgrad(const float* dv, const float* x0, int n0, const float* x1, float* dW, float* db, float* partial,
+void launch_conv1_wgrad(int dt, const void* dv, const float* x0, int n0, const float* x1, float* dW, float* db, float* partial,
                         int B, int S, int C, hipStream_t s) {
     const int nstrips = B * (S / 2 / 8);
     const int nch = nstrips < 1024 ? nstrips : 1024;
-    hipLaunchKernelGGL(k_conv1_wgrad, dim3(nch), dim3(256), 0, s, dv, x0, n0, x1, partial, S, nstrips);
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_conv1_wgrad<T>, dim3(nch), dim3(256), 0, s, (const T*)dv, x0, n0, x1, partial, S, nstrips));
     hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 17, 64)), dim3(1024), 0, s, partial, nch, C * 17, dW, C * 16, db);
 }
 
@@ -891,7 +920,8 @@ void launch_conv1_wgrad(const float* dv, const float* x0, int n0, const float* x
 // blocks: block (a, b) = image pixels (2a..2a+1, 2b..2b+1) needs dv rows a-1..a+1, cols b-1..b+1 and
 // every tap exactly once (ih = 2a: kh 1 -> oh a, kh 3 -> oh a-1; ih = 2a+1: kh 0 -> oh a+1, kh 2 -> oh a).
 // 16 channel lanes x 16 columns per block, RA block rows per thread (sliding 3-row window).
-__global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const float* __restrict__ dv, const float* __restrict__ W,
+template <class T>
+__global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const T* __restrict__ dv, const float* __restrict__ W,
                                                           const float* __restrict__ img, float* __restrict__ dpre, int S) {
     constexpr int RA = 4, C = 64;
     const int Ho = S >> 1, nbb = Ho >> 4, nba = Ho / RA;
@@ -905,7 +935,7 @@ __global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const float* __restric
     f4v w[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const f4v*>(sw + t * (C + 4) + q * 4);
-    const float* base = dv + (size_t)n * Ho * Ho * C + q * 4;
+    const T* base = dv + (size_t)n * Ho * Ho * C + q * 4;
     f4v g[RA + 2][3];
 #pragma unroll
     for (int r = 0; r < RA + 2; ++r) {
@@ -913,7 +943,7 @@ __global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const float* __restric
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int ow = b + k - 1, wc = clampi(ow, Ho - 1);
-            const f4v t = ldg4(base + ((size_t)oc * Ho + wc) * C);
+            const f4v t = ld4<T>(base + ((size_t)oc * Ho + wc) * C);
             g[r][k] = (oh == oc && ow == wc) ? t : f4v{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -948,11 +978,11 @@ __global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const float* __restric
     }
 #undef DOT4
 }
-void launch_conv1_dgrad_tanh(const float* dv, const float* W, const float* img, float* dpre, int B, int S, int C,
+void launch_conv1_dgrad_tanh(int dt, const void* dv, const float* W, const float* img, float* dpre, int B, int S, int C,
                              hipStream_t s) {
     (void)C;
     const int Ho = S / 2;
-    hipLaunchKernelGGL(k_conv1_dgrad_tanh, dim3(B * (Ho / 4) * (Ho / 16)), dim3(256), 0, s, dv, W, img, dpre, S);
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_conv1_dgrad_tanh<T>, dim3(B * (Ho / 4) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, W, img, dpre, S));
 }
 
 // =========================================================================================
@@ -968,32 +998,34 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += sh[k];
     return s;
 }
-__global__ __launch_bounds__(256) void k_cls_fwd(const float* __restrict__ act, const float* __restrict__ wcp,
+template <class T>
+__global__ __launch_bounds__(256) void k_cls_fwd(const T* __restrict__ act, const float* __restrict__ wcp,
                                                  const float* __restrict__ bc, float* __restrict__ logits, int F) {
     __shared__ float sh[4];
-    const float4* a = (const float4*)(act + (size_t)blockIdx.x * F);
+    const T* a = act + (size_t)blockIdx.x * F;
     const float4* w = (const float4*)wcp;
     float acc = 0.f;
     for (int i = threadIdx.x; i < F / 4; i += 256) {
-        const float4 x = a[i], y = w[i];
+        const float4 x = f4(ld4<T>(a + i * 4)), y = w[i];
         acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
     }
     const float s = block_sum(acc, sh);
     if (threadIdx.x == 0) logits[blockIdx.x] = s + bc[0];
 }
-void launch_cls_fwd(const float* act, const float* wcp, const float* bc, float* logits, int B, int F, hipStream_t s) {
-    hipLaunchKernelGGL(k_cls_fwd, dim3(B), dim3(256), 0, s, act, wcp, bc, logits, F);
+void launch_cls_fwd(int dt, const void* act, const float* wcp, const float* bc, float* logits, int B, int F, hipStream_t s) {
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_cls_fwd<T>, dim3(B), dim3(256), 0, s, (const T*)act, wcp, bc, logits, F));
 }
-__global__ void k_cls_features(const float* __restrict__ act, float* __restrict__ feat, int64_t total, int C) {
+template <class T>
+__global__ void k_cls_features(const T* __restrict__ act, float* __restrict__ feat, int64_t total, int C) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // i over [n][c][hw] (torch order)
     if (i >= total) return;
     const int hw = (int)(i % 16), c = (int)((i / 16) % C);
     const int64_t n = i / (16 * (int64_t)C);
-    feat[i] = act[(n * 16 + hw) * C + c];
+    feat[i] = ld1<T>(act + (n * 16 + hw) * C + c);
 }
-void launch_cls_features(const float* act, float* feat, int B, int C, hipStream_t s) {
+void launch_cls_features(int dt, const void* act, float* feat, int B, int C, hipStream_t s) {
     const int64_t total = (int64_t)B * 16 * C;
-    hipLaunchKernelGGL(k_cls_features, dim3(cdiv(total, 256)), dim3(256), 0, s, act, feat, total, C);
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_cls_features<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T*)act, feat, total, C));
 }
 
 __device__ __forceinline__ float bce_dlogit(float x, float y, float inv_count);
@@ -1001,7 +1033,7 @@ __device__ __forceinline__ float bce_dlogit(float x, float y, float inv_count);
 // log clamped at -100; grad_p = (p - y) / max((1 - p) * p, 1e-12) / count; dlogit = grad_p * p * (1 - p))
 __global__ __launch_bounds__(256) void k_bce(const float* __restrict__ logits, int B, int n0, float y0, float y1,
                                              float* __restrict__ probs, float* __restrict__ dlogit,
-                                             float* __restrict__ metrics, int is_g) {
+                                             float* __restrict__ metrics, int is_g, float gscale) {
     __shared__ float sh[4];
     float l0 = 0.f, l1 = 0.f, p0 = 0.f, p1 = 0.f, a0 = 0.f, a1 = 0.f;
     const float c0 = 1.0f / (float)(n0 > 0 ? n0 : 1), c1 = 1.0f / (float)(B - n0 > 0 ? B - n0 : 1);
@@ -1013,7 +1045,7 @@ __global__ __launch_bounds__(256) void k_bce(const float* __restrict__ logits, i
         const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);
         const float loss = -(y * lp + (1.0f - y) * lq);
         if (probs) probs[n] = p;
-        if (dlogit) dlogit[n] = bce_dlogit(x, y, s0 ? c0 : c1);
+        if (dlogit) dlogit[n] = bce_dlogit(x, y, s0 ? c0 : c1) * gscale;
         if (s0) { l0 += loss; p0 += p; a0 += p > 0.5f ? 1.f : 0.f; }
         else    { l1 += loss; p1 += p; a1 += p < 0.5f ? 1.f : 0.f; }
     }
@@ -1030,8 +1062,8 @@ __global__ __launch_bounds__(256) void k_bce(const float* __restrict__ logits, i
     }
 }
 void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* probs, float* dlogit, float* metrics,
-                int is_g_step, hipStream_t s) {
-    hipLaunchKernelGGL(k_bce, dim3(1), dim3(256), 0, s, logits, B, n0, y0, y1, probs, dlogit, metrics, is_g_step);
+                int is_g_step, hipStream_t s, float gscale) {
+    hipLaunchKernelGGL(k_bce, dim3(1), dim3(256), 0, s, logits, B, n0, y0, y1, probs, dlogit, metrics, is_g_step, gscale);
 }
 
 // d(logit) of sigmoid + BCE(mean) for row n, k_bce's own expression (so both kernels agree bit for bit)
@@ -1042,28 +1074,31 @@ __device__ __forceinline__ float bce_dlogit(float x, float y, float inv_count) {
 }
 // d(classifier input) * leaky'(a) * dropout.  Takes the logits, not d(logit): the backward chain then does not
 // wait for k_bce (metrics + d(logit) for the classifier's weight gradient), which runs beside it.
+template <class T>
 __global__ void k_cls_bwd(const float* __restrict__ logits, int B, int n0, float y0, float y1, const float* __restrict__ wcp,
-                          const float* __restrict__ act, const float* __restrict__ noise, float slope, float* __restrict__ dv,
-                          int64_t total, int C) {
+                          const T* __restrict__ act, const float* __restrict__ noise, float slope, T* __restrict__ dv,
+                          int64_t total, int C, float gscale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int F = 16 * C;
     const int j = (int)(i % F), c = j % C;
     const int64_t n = i / F;
     const bool s0 = n < n0;
-    const float dl = bce_dlogit(logits[n], s0 ? y0 : y1, 1.0f / (float)(s0 ? (n0 > 0 ? n0 : 1) : (B - n0 > 0 ? B - n0 : 1)));
-    float g = dl * wcp[j] * (act[i] > 0.f ? 1.f : slope);
+    const float dl = bce_dlogit(logits[n], s0 ? y0 : y1, 1.0f / (float)(s0 ? (n0 > 0 ? n0 : 1) : (B - n0 > 0 ? B - n0 : 1))) * gscale;
+    float g = dl * wcp[j] * (ld1<T>(act + i) > 0.f ? 1.f : slope);
     if (noise) g *= noise[n * C + c];
-    dv[i] = g;
+    st1<T>(dv + i, g);
 }
-void launch_cls_bwd(const float* logits, int n0, float y0, float y1, const float* wcp, const float* act, const float* noise,
-                    float slope, float* dv, int B, int C, hipStream_t s) {
+void launch_cls_bwd(int dt, const float* logits, int n0, float y0, float y1, const float* wcp, const void* act, const float* noise,
+                    float slope, void* dv, int B, int C, hipStream_t s, float gscale) {
     const int64_t total = (int64_t)B * 16 * C;
-    hipLaunchKernelGGL(k_cls_bwd, dim3(cdiv(total, 256)), dim3(256), 0, s, logits, B, n0, y0, y1, wcp, act, noise, slope, dv, total, C);
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_cls_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, logits, B, n0, y0, y1, wcp,
+                                                (const T*)act, noise, slope, (T*)dv, total, C, gscale));
 }
 // dWc[f] = sum_n dlogit[n] * act[n][f'], dbc = sum_n dlogit[n]: 64 features x 4 row lanes per block (rows n = lane, lane + 4,
 // ...), the four partial sums are added in lane order through LDS
-__global__ __launch_bounds__(256) void k_cls_wgrad(const float* __restrict__ dlogit, const float* __restrict__ act, float* __restrict__ dWc,
+template <class T>
+__global__ __launch_bounds__(256) void k_cls_wgrad(const float* __restrict__ dlogit, const T* __restrict__ act, float* __restrict__ dWc,
                             float* __restrict__ dbc, int B, int C) {
     __shared__ float sh[4][64];
     const int F = 16 * C;
@@ -1071,7 +1106,7 @@ __global__ __launch_bounds__(256) void k_cls_wgrad(const float* __restrict__ dlo
     float acc = 0.f;
     if (j < F) {
 #pragma unroll 8
-        for (int n = rl; n < B; n += 4) acc = fmaf(dlogit[n], act[(size_t)n * F + j], acc);
+        for (int n = rl; n < B; n += 4) acc = fmaf(dlogit[n], ld1<T>(act + (size_t)n * F + j), acc);
     } else if (j == F) {
         for (int n = rl; n < B; n += 4) acc += dlogit[n];
     }
@@ -1081,8 +1116,18 @@ __global__ __launch_bounds__(256) void k_cls_wgrad(const float* __restrict__ dlo
     const float t = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
     if (j < F) dWc[(j % C) * 16 + j / C] = t; else dbc[0] = t;
 }
-void launch_cls_wgrad(const float* dlogit, const float* act, float* dWc, float* dbc, int B, int C, hipStream_t s) {
-    hipLaunchKernelGGL(k_cls_wgrad, dim3(cdiv(16 * C + 1, 64)), dim3(256), 0, s, dlogit, act, dWc, dbc, B, C);
+void launch_cls_wgrad(int dt, const float* dlogit, const void* act, float* dWc, float* dbc, int B, int C, hipStream_t s) {
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_cls_wgrad<T>, dim3(cdiv(16 * C + 1, 64)), dim3(256), 0, s, dlogit, (const T*)act, dWc, dbc, B, C));
+}
+
+// test hook / operator entries: element-type conversion of a whole tensor
+template <class T>
+__global__ void k_to_f32(const T* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = ld1<T>(src + i);
+}
+void launch_to_f32(int dt, const void* src, float* dst, int64_t n, hipStream_t s) {
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_to_f32<T>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const T*)src, dst, n));
 }
 
 // =========================================================================================

@@ -37,8 +37,24 @@ static int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(SIGGAN_E_HIP, "kernel launch -> %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// Entry points run on the context's device and put the caller's current device back on return (a process whose
+// torch current device is another GPU must not find it switched behind its back).
+struct DevGuard {
+    int prev = -1, dev;
+    hipError_t err = hipSuccess;
+    explicit DevGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DevGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+
 static const float BN_MOMENTUM = 0.1f, BN_EPS = 1e-5f;   // nn.BatchNorm defaults (generator_vanilla_gan.py:58,126)
 static const int MAXL = 6;
+#define ENTER(c)                                                     \
+    if (!(c)) return fail(SIGGAN_E_INVALID, "null context");          \
+    DevGuard dg_((c)->cfg.device);                                    \
+    HIPCHK(dg_.err)
 
 static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -57,6 +73,9 @@ struct PhaseKey {
 struct siggan_ctx {
     siggan_config cfg;
     int S, latent, Lg, Ld, Bm;
+    int dt;             // element type of the activation / gradient tensors and of the MFMA weight packs (act.h)
+    size_t es;          // its size in bytes
+    float gscale;       // gradient scale of the backward chains (fp16: keeps small gradients out of the subnormals; else 1)
     int gC[MAXL + 1];   // generator channel chain gC[0..Lg]  (generator_vanilla_gan.py:131-149)
     int dC[MAXL + 1];   // discriminator chain dC[0]=1, dC[1..Ld] (discriminator_vanilla_gan.py:131-194)
     int F;              // gC[0]*16
@@ -69,12 +88,17 @@ struct siggan_ctx {
     bool g_dirty, d_dirty;
     // workspace
     char* ws; size_t ws_bytes;
-    float *z, *fc_y, *g_y[MAXL + 1], *g_a[MAXL + 1], *g_da[MAXL + 1], *g_bn[MAXL + 1], *g_bne[MAXL + 1];
+    // (element type dt: fc_y, g_y, g_a, g_da, d_a, d_dv and the MFMA weight packs g_up, g_dn, d_dn, d_up; fp32: the rest)
+    float *z, *g_bn[MAXL + 1], *g_bne[MAXL + 1];
+    char *fc_y, *g_y[MAXL + 1], *g_a[MAXL + 1], *g_da[MAXL + 1];
     float *img, *dpre;
-    float *d_a[MAXL + 1], *d_dv[MAXL + 1], *d_noise[MAXL + 1];
+    char *d_a[MAXL + 1], *d_dv[MAXL + 1];
+    float *d_noise[MAXL + 1];
     float *logits, *probs, *dlogit;
-    float *g_up[MAXL + 1], *g_dn[MAXL + 1], *d_dn[MAXL + 1], *d_up[MAXL + 1], *wcp;
-    float *slab, *slab_k, *slab_k2, *partial, *partial_b, *partial_c, *z_g, *img_g, *metrics, *op_pack, *zeros, *wfc_t, *real_stage, *real_next, *mask_stage;
+    char *g_up[MAXL + 1], *g_dn[MAXL + 1], *d_dn[MAXL + 1], *d_up[MAXL + 1];
+    float *wcp;
+    float *slab, *slab_k, *slab_k2, *partial, *partial_b, *partial_c, *z_g, *img_g, *metrics, *zeros, *wfc_t, *real_stage, *real_next, *mask_stage;
+    char *op_pack;
     int64_t slab_floats, slab_k_floats;
     DevState* dev;
     // last *_grads call (for *_apply)
@@ -85,6 +109,8 @@ struct siggan_ctx {
     int mode;
     hipStream_t s_m, s_a, s_b, s_c;
     hipEvent_t ev_gfwd, ev_dreal;
+    bool dreal_orphan;   // a D(real) forward enqueued on lane c was abandoned: the next enqueue waits for ev_dreal first
+    hipError_t lane_err; // first failed event record / wait of a fork or join (checked after every phase)
     int staged_B;        // batch of a real batch staged for the NEXT D step by siggan_stage_real (0: none)
     int dreal_B;         // batch whose D(real) forward siggan_g_grads already enqueued on lane c (0: none)
     int zg_stash;        // batch of an explicit G-step z handed to siggan_step_begin when the forward was not pipelined
@@ -158,10 +184,19 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     if (cfg->latent_dim < 1 || cfg->latent_dim > 4096) return fail(SIGGAN_E_INVALID, "latent_dim out of range: %d", cfg->latent_dim);
     if (cfg->max_batch < 1 || cfg->max_batch > 4096) return fail(SIGGAN_E_INVALID, "max_batch out of range: %d", cfg->max_batch);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return fail(SIGGAN_E_INVALID, "dropout must be in [0,1)");
-    HIPCHK(hipSetDevice(cfg->device));
+    if (cfg->dtype != SIGGAN_DTYPE_F32 && cfg->dtype != SIGGAN_DTYPE_BF16 && cfg->dtype != SIGGAN_DTYPE_F16)
+        return fail(SIGGAN_E_INVALID, "dtype must be SIGGAN_DTYPE_F32, _BF16 or _F16, got %d", cfg->dtype);
+    if (!(cfg->f16_grad_scale >= 0.f) || cfg->f16_grad_scale > 65536.f)
+        return fail(SIGGAN_E_INVALID, "f16_grad_scale must be in [0, 65536] (0 = default)");
+    DevGuard dg(cfg->device);
+    HIPCHK(dg.err);
     siggan_ctx* c = new (std::nothrow) siggan_ctx();
     if (!c) return fail(SIGGAN_E_NOMEM, "out of host memory");
     c->cfg = *cfg; c->S = cfg->image_size; c->latent = cfg->latent_dim; c->Bm = cfg->max_batch;
+    c->dt = cfg->dtype; c->es = dt_size(c->dt);
+    // fp16 stores activation gradients of order 1e-7..1e-3: a power-of-two scale (exact to apply and to remove) lifts
+    // them clear of the fp16 subnormals; bf16 has fp32's exponent range and needs none
+    c->gscale = c->dt == DT_F16 ? (cfg->f16_grad_scale > 0.f ? cfg->f16_grad_scale : 1024.f) : 1.0f;
     c->bound = false; c->g_dirty = c->d_dirty = true; c->pending = 0; c->metrics_last = nullptr;
     build_layout(c);
 
@@ -173,17 +208,21 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         if (base) *p = (float*)(base + off);
         off += ((size_t)nfloats * sizeof(float) + 255) & ~(size_t)255;
     };
+    auto carve_t = [&](char** p, int64_t nelem) {          // a tensor of the context's element type
+        if (base) *p = base + off;
+        off += ((size_t)nelem * c->es + 255) & ~(size_t)255;
+    };
     c->slab_floats = (int64_t)16 << 20;
     c->slab_k_floats = (int64_t)16 << 20;
     for (int pass = 0; pass < 2; ++pass) {
         off = 0;
         carve(&c->z, Bm * c->latent);
-        carve(&c->fc_y, Bm * c->F);
+        carve_t(&c->fc_y, Bm * c->F);
         for (int l = 0; l <= c->Lg; ++l) {
             const int64_t H = 4 << l, n = Bm * H * H * c->gC[l];
-            if (l == 0) c->g_y[0] = c->fc_y; else carve(&c->g_y[l], n);
-            carve(&c->g_a[l], n);
-            carve(&c->g_da[l], n);
+            if (l == 0) c->g_y[0] = c->fc_y; else carve_t(&c->g_y[l], n);
+            carve_t(&c->g_a[l], n);
+            carve_t(&c->g_da[l], n);
             carve(&c->g_bn[l], 6 * (int64_t)(l == 0 ? c->F : c->gC[l]));
             carve(&c->g_bne[l], 4 * (int64_t)(l == 0 ? c->F : c->gC[l]));   // eval-mode [scale|shift|mean|rstd]
         }
@@ -192,18 +231,18 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->dpre, Bm * c->S * c->S);
         for (int l = 1; l <= c->Ld; ++l) {
             const int64_t H = c->S >> l, n = Bd * H * H * c->dC[l];
-            carve(&c->d_a[l], n);
-            carve(&c->d_dv[l], n);
+            carve_t(&c->d_a[l], n);
+            carve_t(&c->d_dv[l], n);
             carve(&c->d_noise[l], Bd * c->dC[l]);
         }
         carve(&c->logits, Bd); carve(&c->probs, Bd); carve(&c->dlogit, Bd);
         for (int l = 1; l <= c->Lg; ++l) {
-            carve(&c->g_up[l], (int64_t)c->gC[l - 1] * c->gC[l] * 16);
-            carve(&c->g_dn[l], (int64_t)c->gC[l - 1] * c->gC[l] * 16);
+            carve_t(&c->g_up[l], (int64_t)c->gC[l - 1] * c->gC[l] * 16);
+            carve_t(&c->g_dn[l], (int64_t)c->gC[l - 1] * c->gC[l] * 16);
         }
         for (int l = 2; l <= c->Ld; ++l) {
-            carve(&c->d_dn[l], (int64_t)c->dC[l - 1] * c->dC[l] * 16);
-            carve(&c->d_up[l], (int64_t)c->dC[l - 1] * c->dC[l] * 16);
+            carve_t(&c->d_dn[l], (int64_t)c->dC[l - 1] * c->dC[l] * 16);
+            carve_t(&c->d_up[l], (int64_t)c->dC[l - 1] * c->dC[l] * 16);
         }
         carve(&c->wcp, (int64_t)c->dC[c->Ld] * 16);
         carve(&c->slab, c->slab_floats);
@@ -218,7 +257,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->real_next, Bm * c->S * c->S);
         { int64_t sumC = 0; for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l]; carve(&c->mask_stage, 2 * Bm * sumC); }
         carve(&c->metrics, SIGGAN_M_COUNT);
-        carve(&c->op_pack, (int64_t)512 * 512 * 16);
+        carve_t(&c->op_pack, (int64_t)512 * 512 * 16);
         carve(&c->zeros, 64);
         carve(&c->wfc_t, (int64_t)c->F * c->latent);
         float* devp = nullptr;
@@ -244,6 +283,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_gfwd, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_dreal, hipEventDisableTiming));
     c->staged_B = c->dreal_B = 0;
+    c->dreal_orphan = false; c->lane_err = hipSuccess;
     c->g_fwd_pending = 0;
     c->zg_stash = 0;
     for (int i = 0; i < siggan_ctx::NEV; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
@@ -254,7 +294,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
 
 extern "C" int siggan_destroy(siggan_ctx* c) {
     if (!c) return SIGGAN_OK;
-    (void)hipSetDevice(c->cfg.device);
+    DevGuard dg(c->cfg.device);
     (void)hipDeviceSynchronize();
     for (auto& e : c->graphs) (void)hipGraphExecDestroy(e.second);
     for (int i = 0; i < siggan_ctx::NEV; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -264,6 +304,7 @@ extern "C" int siggan_destroy(siggan_ctx* c) {
     if (c->s_b) (void)hipStreamDestroy(c->s_b);
     if (c->s_c) (void)hipStreamDestroy(c->s_c);
     if (c->ev_gfwd) (void)hipEventDestroy(c->ev_gfwd);
+    if (c->ev_dreal) (void)hipEventDestroy(c->ev_dreal);
     if (c->ws) (void)hipFree(c->ws);
     delete c;
     return SIGGAN_OK;
@@ -285,6 +326,20 @@ extern "C" int64_t siggan_bn_count(const siggan_ctx* c) { return c ? c->bn_total
 extern "C" int32_t siggan_bn_layers(const siggan_ctx* c) { return c ? c->Lg + 1 : -1; }
 extern "C" int64_t siggan_workspace_bytes(const siggan_ctx* c) { return c ? (int64_t)c->ws_bytes : -1; }
 
+// A D(real) forward that siggan_g_grads started ahead of time on lane c (siggan_stage_real) and that no D step will
+// consume still reads the staged batch, the D weight packs and slab_k2 and writes activation rows [0,B): whoever
+// abandons it marks it orphaned, and the next call that enqueues anything first makes its stream wait for that lane.
+static void drop_dreal(siggan_ctx* c) {
+    if (c->dreal_B) { c->dreal_orphan = true; c->dreal_B = 0; }
+}
+static int settle(siggan_ctx* c, hipStream_t s) {
+    if (c->dreal_orphan) {
+        HIPCHK(hipStreamWaitEvent(s, c->ev_dreal, 0));
+        c->dreal_orphan = false;
+    }
+    return SIGGAN_OK;
+}
+
 extern "C" int siggan_bind(siggan_ctx* c, const siggan_storage* st) {
     if (!c || !st) return fail(SIGGAN_E_INVALID, "null argument");
     const void* need[] = {st->g_params, st->g_bn_running_mean, st->g_bn_running_var, st->d_params};
@@ -295,21 +350,32 @@ extern "C" int siggan_bind(siggan_ctx* c, const siggan_storage* st) {
     for (const void* p : all)
         if (((uintptr_t)p & 15) != 0) return fail(SIGGAN_E_INVALID, "siggan_bind: arenas must be 16-byte aligned");
     c->st = *st;
-    c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0; c->staged_B = c->dreal_B = 0;
+    c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0; c->staged_B = 0;
+    drop_dreal(c);
     return SIGGAN_OK;
 }
 extern "C" int siggan_params_changed(siggan_ctx* c) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     c->g_dirty = c->d_dirty = true;
-    c->dreal_B = 0;                    // a D(real) forward started ahead of time used the old weights
+    drop_dreal(c);                     // a D(real) forward started ahead of time used the old weights
     return SIGGAN_OK;
 }
 extern "C" int siggan_seed(siggan_ctx* c, uint64_t seed, uint64_t offset) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
-    HIPCHK(hipSetDevice(c->cfg.device));
+    DevGuard dg_(c->cfg.device); HIPCHK(dg_.err);
     unsigned long long v[2] = {seed, offset};
     HIPCHK(hipMemcpy(c->dev, v, sizeof v, hipMemcpyHostToDevice));   // seed, rng_ctr are the first two fields
-    c->dreal_B = 0;                    // its dropout tables were drawn from the old stream
+    drop_dreal(c);                     // its dropout tables were drawn from the old stream
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_rng_state(siggan_ctx* c, uint64_t* seed, uint64_t* offset) {
+    ENTER(c);
+    if (!seed || !offset) return fail(SIGGAN_E_INVALID, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long v[2];
+    HIPCHK(hipMemcpy(v, c->dev, sizeof v, hipMemcpyDeviceToHost));
+    *seed = v[0]; *offset = v[1];
     return SIGGAN_OK;
 }
 
@@ -320,8 +386,6 @@ static int check_call(siggan_ctx* c, int batch, bool need_bound = true) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     if (need_bound && !c->bound) return fail(SIGGAN_E_STATE, "siggan_bind has not been called");
     if (batch < 1 || batch > c->Bm) return fail(SIGGAN_E_INVALID, "batch %d outside [1, max_batch=%d]", batch, c->Bm);
-    hipError_t e = hipSetDevice(c->cfg.device);
-    if (e != hipSuccess) return fail(SIGGAN_E_HIP, "hipSetDevice -> %s", hipGetErrorString(e));
     return SIGGAN_OK;
 }
 
@@ -329,17 +393,17 @@ static int check_call(siggan_ctx* c, int batch, bool need_bound = true) {
 // (for G) the BatchNorm eval-mode scale/shift tables.  sg / sd: the lanes the two launches go to.
 static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, bool do_d) {
     if (do_g) {
-        PrepTable t; t.njobs = 0;
+        PrepTable t; t.njobs = 0; t.overflow = 0;
         PrepJob j; memset(&j, 0, sizeof j);
         j.type = PREP_FC_T; j.O = c->latent; j.I = c->gC[0]; j.src = GP(c, gi_fc_w()); j.dst = c->wfc_t;
         prep_add(t, j, (long long)c->latent * c->F);
         for (int l = 1; l <= c->Lg; ++l) {
             const long long n = (long long)c->gC[l - 1] * c->gC[l] * 16;
             memset(&j, 0, sizeof j);
-            j.src = GP(c, gi_up_w(l));                                 // (Cin, Cout, 4, 4)
-            j.type = PREP_PACK_UP; j.I = c->gC[l - 1]; j.O = c->gC[l]; j.dst = c->g_up[l];   // forward: contract Cin
+            j.src = GP(c, gi_up_w(l)); j.dt = c->dt;                   // (Cin, Cout, 4, 4)
+            j.type = PREP_PACK_UP; j.I = c->gC[l - 1]; j.O = c->gC[l]; j.dst = (float*)c->g_up[l];   // forward: contract Cin
             prep_add(t, j, n);
-            j.type = PREP_PACK_DOWN; j.O = c->gC[l - 1]; j.I = c->gC[l]; j.dst = c->g_dn[l]; // input-gradient: out = Cin
+            j.type = PREP_PACK_DOWN; j.O = c->gC[l - 1]; j.I = c->gC[l]; j.dst = (float*)c->g_dn[l]; // input-gradient: out = Cin
             prep_add(t, j, n);
         }
         for (int l = 0; l <= c->Lg; ++l) {
@@ -351,24 +415,24 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
             j.dst = c->g_bne[l];
             prep_add(t, j, C);
         }
-        launch_prepare(t, BN_EPS, sg);
+        if (!launch_prepare(t, BN_EPS, sg)) c->lane_err = hipErrorInvalidValue;   // table overflow: reported by the caller
     }
     if (do_d) {
-        PrepTable t; t.njobs = 0;
+        PrepTable t; t.njobs = 0; t.overflow = 0;
         PrepJob j;
         for (int l = 2; l <= c->Ld; ++l) {
             const long long n = (long long)c->dC[l - 1] * c->dC[l] * 16;
             memset(&j, 0, sizeof j);
-            j.src = DP(c, di_w(l));                                    // (Cout, Cin, 4, 4)
-            j.type = PREP_PACK_DOWN; j.O = c->dC[l]; j.I = c->dC[l - 1]; j.dst = c->d_dn[l];  // forward
+            j.src = DP(c, di_w(l)); j.dt = c->dt;                      // (Cout, Cin, 4, 4)
+            j.type = PREP_PACK_DOWN; j.O = c->dC[l]; j.I = c->dC[l - 1]; j.dst = (float*)c->d_dn[l];  // forward
             prep_add(t, j, n);
-            j.type = PREP_PACK_UP; j.I = c->dC[l]; j.O = c->dC[l - 1]; j.dst = c->d_up[l];    // input-gradient: contract Cout
+            j.type = PREP_PACK_UP; j.I = c->dC[l]; j.O = c->dC[l - 1]; j.dst = (float*)c->d_up[l];    // input-gradient: contract Cout
             prep_add(t, j, n);
         }
         memset(&j, 0, sizeof j);
         j.type = PREP_CLS; j.O = c->dC[c->Ld]; j.src = DP(c, di_cls_w(c)); j.dst = c->wcp;
         prep_add(t, j, (long long)c->dC[c->Ld] * 16);
-        launch_prepare(t, BN_EPS, sd);
+        if (!launch_prepare(t, BN_EPS, sd)) c->lane_err = hipErrorInvalidValue;
     }
 }
 
@@ -378,6 +442,11 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
 // overlap off all three are the same stream and fork/join are no-ops.  Forks and joins are plain
 // event record / wait pairs, so the same code runs eagerly and under stream capture (hipGraph).
 // ------------------------------------------------------------------------------------------
+static int lane_check(siggan_ctx* c) {
+    if (c->lane_err == hipSuccess) return SIGGAN_OK;
+    const hipError_t e = c->lane_err; c->lane_err = hipSuccess;
+    return fail(SIGGAN_E_HIP, "an event record / stream wait / prepare table of the step failed: %s", hipGetErrorString(e));
+}
 struct Lanes {
     siggan_ctx* c;
     hipStream_t m, a, b;
@@ -385,17 +454,22 @@ struct Lanes {
     void fork(hipStream_t to) {          // `to` waits for everything enqueued on m so far
         if (to == m) return;
         hipEvent_t e = next();
-        (void)hipEventRecord(e, m); (void)hipStreamWaitEvent(to, e, 0);
+        note(hipEventRecord(e, m)); note(hipStreamWaitEvent(to, e, 0));
     }
     void join(hipStream_t from) {        // m waits for everything enqueued on `from`
         if (from == m) return;
         hipEvent_t e = next();
-        (void)hipEventRecord(e, from); (void)hipStreamWaitEvent(m, e, 0);
+        note(hipEventRecord(e, from)); note(hipStreamWaitEvent(m, e, 0));
     }
+    // a failed record / wait would silently drop an ordering edge: remember the first one, run_phase reports it
+    void note(hipError_t e) { if (e != hipSuccess && c->lane_err == hipSuccess) c->lane_err = e; }
+    void record(hipEvent_t e, hipStream_t s) { note(hipEventRecord(e, s)); }
+    void wait(hipStream_t s, hipEvent_t e) { note(hipStreamWaitEvent(s, e, 0)); }
 };
 
 static GConvArgs gconv_args(siggan_ctx* c) {
     GConvArgs a; memset(&a, 0, sizeof a);
+    a.dt = c->dt;
     a.slab = c->slab_k; a.slab_floats = c->slab_k_floats; a.zeros = c->zeros;
     return a;
 }
@@ -407,13 +481,13 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
                            float* partial = nullptr, float* slab_k = nullptr, uint32_t rng_sid = 0, float* z_out = nullptr) {
     if (!partial) partial = c->partial;
     if (!training) {     // eval: BatchNorm1d + ReLU folded into the fc epilogue
-        launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->g_a[0], B, c->latent, c->gC[0], s, c->g_bne[0], c->dev, rng_sid, z_out);
+        launch_fc_fwd(c->dt, z, c->wfc_t, GP(c, gi_fc_b()), c->g_a[0], B, c->latent, c->gC[0], s, c->g_bne[0], c->dev, rng_sid, z_out);
     } else {
-        launch_fc_fwd(z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s, nullptr, c->dev, rng_sid, z_out);
-        launch_bn_train_stats(c->fc_y, B, c->F, GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), c->st.g_bn_running_mean,
+        launch_fc_fwd(c->dt, z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s, nullptr, c->dev, rng_sid, z_out);
+        launch_bn_train_stats(c->dt, c->fc_y, B, c->F, GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), c->st.g_bn_running_mean,
                               c->st.g_bn_running_var, c->st.g_bn_batches, c->g_bn[0], partial, c->gC[0], BN_MOMENTUM,
                               BN_EPS, s);
-        launch_bn_relu(c->fc_y, c->g_a[0], B, c->F, c->g_bn[0], s);
+        launch_bn_relu(c->dt, c->fc_y, c->g_a[0], B, c->F, c->g_bn[0], s);
     }
     for (int l = 1; l <= c->Lg; ++l) {
         const int Hi = 4 << (l - 1), Ci = c->gC[l - 1], Co = c->gC[l];
@@ -427,16 +501,16 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
             a.out = c->g_y[l]; a.epi = EPI_RAW;
             launch_gconv(a, s);
             const int64_t R = (int64_t)B * 4 * Hi * Hi;
-            launch_bn_train_stats(c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
+            launch_bn_train_stats(c->dt, c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
                                   c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
                                   BN_MOMENTUM, BN_EPS, s);
-            launch_bn_relu(c->g_y[l], c->g_a[l], R, C, c->g_bn[l], s);
+            launch_bn_relu(c->dt, c->g_y[l], c->g_a[l], R, C, c->g_bn[l], s);
         } else {
             a.out = c->g_a[l]; a.epi = EPI_AFFINE_RELU; a.scale = c->g_bne[l]; a.shift = c->g_bne[l] + C;
             launch_gconv(a, s);
         }
     }
-    launch_final_fwd(c->g_a[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
+    launch_final_fwd(c->dt, c->g_a[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
 }
 
 // Discriminator conv blocks + classifier logits for nB images written to workspace rows
@@ -444,9 +518,9 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
 // produces the fakes, then D(fake) into rows [B,2B); backward treats the 2B rows as one batch).
 static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool dropout, hipStream_t s, float* slab_k) {
     const float slope = c->cfg.leaky_slope;
-    auto act = [&](int l) { const int64_t H = c->S >> l; return c->d_a[l] + (int64_t)r0 * H * H * c->dC[l]; };
+    auto act = [&](int l) { const int64_t H = c->S >> l; return c->d_a[l] + (size_t)((int64_t)r0 * H * H * c->dC[l]) * c->es; };
     auto nz = [&](int l) { return dropout ? c->d_noise[l] + (int64_t)r0 * c->dC[l] : nullptr; };
-    launch_conv1_fwd(x, nB, x, DP(c, di_w(1)), DP(c, di_b(1)), nz(1), slope, act(1), nB, c->S, c->dC[1], s);
+    launch_conv1_fwd(c->dt, x, nB, x, DP(c, di_w(1)), DP(c, di_b(1)), nz(1), slope, act(1), nB, c->S, c->dC[1], s);
     for (int l = 2; l <= c->Ld; ++l) {
         const int Hi = c->S >> (l - 1), Ho = Hi / 2;
         GConvArgs a = gconv_args(c);
@@ -457,7 +531,7 @@ static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool d
         a.epi = EPI_BIAS_LRELU_DROP; a.bias = DP(c, di_b(l)); a.noise = nz(l); a.slope = slope;
         launch_gconv(a, s);
     }
-    launch_cls_fwd(act(c->Ld), c->wcp, DP(c, di_cls_b(c)), c->logits + r0, nB, c->dC[c->Ld] * 16, s);
+    launch_cls_fwd(c->dt, act(c->Ld), c->wcp, DP(c, di_cls_b(c)), c->logits + r0, nB, c->dC[c->Ld] * 16, s);
 }
 
 // Backward through the Discriminator from d(logit).  want_wgrad: fill the D gradient arena
@@ -473,16 +547,16 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
     // sigmoid + BCE: losses / means into the metrics, d(logit) for the classifier's weight gradient -- on lane b; the
     // chain below recomputes d(logit) from the logits and does not wait for it
     L.fork(L.b);
-    launch_bce(c->logits, Bd, bce.n0, bce.y0, bce.y1, c->probs, c->dlogit, bce.mt, bce.is_g, L.b);
-    launch_cls_bwd(c->logits, bce.n0, bce.y0, bce.y1, c->wcp, c->d_a[Ld], dropout ? c->d_noise[Ld] : nullptr, slope, c->d_dv[Ld], Bd,
-                   c->dC[Ld], L.m);
+    launch_bce(c->logits, Bd, bce.n0, bce.y0, bce.y1, c->probs, c->dlogit, bce.mt, bce.is_g, L.b, c->gscale);
+    launch_cls_bwd(c->dt, c->logits, bce.n0, bce.y0, bce.y1, c->wcp, c->d_a[Ld], dropout ? c->d_noise[Ld] : nullptr, slope, c->d_dv[Ld], Bd,
+                   c->dC[Ld], L.m, c->gscale);
     if (want_wgrad)
-        launch_cls_wgrad(c->dlogit, c->d_a[Ld], DG(c, di_cls_w(c)), DG(c, di_cls_b(c)), Bd, c->dC[Ld], L.b);
+        launch_cls_wgrad(c->dt, c->dlogit, c->d_a[Ld], DG(c, di_cls_w(c)), DG(c, di_cls_b(c)), Bd, c->dC[Ld], L.b);
     for (int l = Ld; l >= 2; --l) {
         const int Ho = c->S >> l, Hi = 2 * Ho, Co = c->dC[l], Ci = c->dC[l - 1];
         if (want_wgrad) {
             L.fork(L.a);                                   // d_dv[l] is complete on m here
-            WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
+            WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
             w.S = c->d_dv[l]; w.L = c->d_a[l - 1]; w.slab = c->slab; w.dw = DG(c, di_w(l)); w.B = Bd; w.Cs = Co; w.Cl = Ci;
             w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
             w.db = DG(c, di_b(l));                           // bias gradient = column sums of d(pre-activation): rides in the same kernel
@@ -499,12 +573,12 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
     }
     if (want_wgrad) {
         L.fork(L.b);
-        launch_conv1_wgrad(c->d_dv[1], x0, n0, x1, DG(c, di_w(1)), DG(c, di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
+        launch_conv1_wgrad(c->dt, c->d_dv[1], x0, n0, x1, DG(c, di_w(1)), DG(c, di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
         L.join(L.a);
     }
     L.join(L.b);
     if (want_dimage)
-        launch_conv1_dgrad_tanh(c->d_dv[1], DP(c, di_w(1)), x0, c->dpre, Bd, c->S, c->dC[1], L.m);
+        launch_conv1_dgrad_tanh(c->dt, c->d_dv[1], DP(c, di_w(1)), x0, c->dpre, Bd, c->S, c->dC[1], L.m);
 }
 
 // Backward through the Generator from d(pre-tanh) in c->dpre; fills the G gradient arena.  Lane m:
@@ -512,18 +586,18 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
 static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     const int Lg = c->Lg, S = c->S;
     L.fork(L.b);
-    launch_final_wgrad(c->dpre, c->g_a[Lg], GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), c->partial_b, B, S, c->gC[Lg], L.b);
+    launch_final_wgrad(c->dt, c->dpre, c->g_a[Lg], GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), c->partial_b, B, S, c->gC[Lg], L.b);
     for (int l = Lg; l >= 1; --l) {
         const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
         const int64_t R = (int64_t)B * Ho * Ho;
         if (l == Lg)     // final conv's input-gradient folded into this block's BatchNorm backward
-            launch_final_dgrad_bn_bwd(c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
+            launch_final_dgrad_bn_bwd(c->dt, c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
                                       GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
         else
-            launch_bn_bwd(c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m);
+            launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m);
         L.fork(L.a);                                       // dy[l] is complete on m here
         // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
-        WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
+        WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
         w.S = c->g_a[l - 1]; w.L = c->g_da[l]; w.slab = c->slab; w.dw = GG(c, gi_up_w(l)); w.B = B; w.Cs = Ci; w.Cl = Co;
         w.lgHs = ilog2i(Hi); w.lgWs = w.lgHs; w.lgCl = ilog2i(Co); w.K = B * Hi * Hi;
         const int max_splits = (int)(c->slab_floats / ((int64_t)Ci * (16 * Co + 1)));
@@ -535,9 +609,9 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
         launch_gconv(a, L.m);
     }
-    launch_bn_bwd(c->g_da[0], c->fc_y, B, c->F, c->g_bn[0], c->partial, GG(c, gi_bn0_w()), GG(c, gi_bn0_b()),
+    launch_bn_bwd(c->dt, c->g_da[0], c->fc_y, B, c->F, c->g_bn[0], c->partial, GG(c, gi_bn0_w()), GG(c, gi_bn0_b()),
                   c->gC[0], L.m);
-    launch_fc_wgrad(c->g_da[0], z, GG(c, gi_fc_w()), GG(c, gi_fc_b()), B, c->latent, c->gC[0], L.m);
+    launch_fc_wgrad(c->dt, c->g_da[0], z, GG(c, gi_fc_w()), GG(c, gi_fc_b()), B, c->latent, c->gC[0], L.m);
     L.join(L.a); L.join(L.b);
 }
 
@@ -581,7 +655,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     L.fork(L.a);                                                     // lane a: D's packs, dropout tables, D(real)
     repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
     if (k.pre_real)      // staged batch -> this step's real batch (the D backward reads it again)
-        (void)hipMemcpyAsync(c->real_stage, c->real_next, (size_t)B * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, L.a);
+        L.note(hipMemcpyAsync(c->real_stage, c->real_next, (size_t)B * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, L.a));
     if (drop) make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, k.pre_real == 2 ? 1 : 0, 2, L.a);
     // D(real) beside the Generator (train...py:309) -- unless the previous siggan_g_grads already ran it
     // (siggan_stage_real) beside its Generator backward; then bce only has to wait for that lane
@@ -593,13 +667,13 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // moves the BatchNorm running statistics and reuses the activation buffers; its own image / z /
     // scratch).  It forks HERE but is enqueued after D(fake), whose kernels the dispatcher should see first.
     hipEvent_t e_spec = nullptr;
-    if (k.spec_g) { e_spec = L.next(); (void)hipEventRecord(e_spec, L.m); }
+    if (k.spec_g) { e_spec = L.next(); L.record(e_spec, L.m); }
     d_forward_rows(c, c->img, B, B, drop, L.m, c->slab_k);           // D(fake) into rows [B, 2B)
-    if (k.pre_real == 2) (void)hipStreamWaitEvent(L.m, c->ev_dreal, 0);
+    if (k.pre_real == 2) L.wait(L.m, c->ev_dreal);
     if (k.spec_g) {
-        (void)hipStreamWaitEvent(c->s_c, e_spec, 0);
+        L.wait(c->s_c, e_spec);
         g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2, 2, c->z_g);
-        (void)hipEventRecord(c->ev_gfwd, c->s_c);
+        L.record(c->ev_gfwd, c->s_c);
     }
     d_backward_pass(c, L, c->real_stage, B, c->img, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0});
 }
@@ -609,7 +683,7 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const float* zg; float* img;
     if (k.spec_g) {                                                  // forward already enqueued by siggan_step_begin
         repack(c, L.m, L.m, false, k.d_dirty != 0);
-        (void)hipStreamWaitEvent(L.m, c->ev_gfwd, 0);
+        L.wait(L.m, c->ev_gfwd);
         zg = c->z_g; img = c->img_g;
     } else {
         L.fork(L.a);
@@ -629,7 +703,7 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         L.fork(c->s_c);
         if (drop) make_noise(c, nullptr, B, 0, 1, c->s_c, 1);
         d_forward_rows(c, c->real_next, 0, B, drop, c->s_c, c->slab_k2);
-        (void)hipEventRecord(c->ev_dreal, c->s_c);
+        L.record(c->ev_dreal, c->s_c);
     }
     g_backward_pass(c, L, zg, B);
 }
@@ -644,10 +718,13 @@ static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const int64_t n = which == 0 ? c->g_total : c->d_total;
     const int nt = (int)(which == 0 ? c->g_off.size() : c->d_off.size());
     const bool clip = k.clip > 0.f;
+    // the arena holds gscale x the gradient (fp16 chains; 1 otherwise): the optimiser's multiplier takes it out again, and
+    // the gradient is written back unscaled (as torch leaves a clipped .grad)
+    const float gs = k.gs / c->gscale;
     if (clip) launch_grad_sumsq(g, n, c->dev, c->partial, L.m);
-    launch_adam_prepare(c->dev, steps, nt, k.lr, k.beta1, k.beta2, k.gs, k.clip,
+    launch_adam_prepare(c->dev, steps, nt, k.lr, k.beta1, k.beta2, gs, k.clip,
                         k.mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), L.m);
-    launch_adam(p, g, m, v, n, c->dev, k.beta1, k.beta2, k.eps, (clip || k.gs != 1.0f) ? 1 : 0, L.m);
+    launch_adam(p, g, m, v, n, c->dev, k.beta1, k.beta2, k.eps, (clip || gs != 1.0f) ? 1 : 0, L.m);
 }
 
 static void run_phase_body(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
@@ -666,7 +743,7 @@ static int run_phase(siggan_ctx* c, const PhaseKey& k, hipStream_t u) {
         Lanes L{c, u, overlap ? c->s_a : u, overlap ? c->s_b : u};
         run_phase_body(c, L, k);
         LAUNCHCHK();
-        return SIGGAN_OK;
+        return lane_check(c);
     }
     hipGraphExec_t exec = nullptr;
     for (auto& e : c->graphs)
@@ -727,38 +804,43 @@ extern "C" int siggan_set_mode(siggan_ctx* c, int32_t mode) {
 
 extern "C" int siggan_g_forward(siggan_ctx* c, const float* z_dev, int32_t batch, int32_t training, float* images_dev,
                                 void* stream) {
+    ENTER(c);
     int rc = check_call(c, batch);
     if (rc) return rc;
     if (!z_dev || !images_dev) return fail(SIGGAN_E_INVALID, "null tensor");
     hipStream_t s = (hipStream_t)stream;
+    if ((rc = settle(c, s))) return rc;
     repack(c, s, s, c->g_dirty, c->d_dirty);
     c->g_dirty = c->d_dirty = false;
     g_forward_pass(c, z_dev, batch, training != 0, images_dev, s);
     if (training) c->g_dirty = true;   // running statistics moved: the eval-mode tables are stale
     LAUNCHCHK();
-    return SIGGAN_OK;
+    return lane_check(c);
 }
 
 extern "C" int siggan_d_forward(siggan_ctx* c, const float* x_dev, int32_t batch, int32_t training, const float* masks_dev,
                                 float* probs_dev, float* features_dev, void* stream) {
+    ENTER(c);
     int rc = check_call(c, batch);
     if (rc) return rc;
     if (!x_dev || (!probs_dev && !features_dev)) return fail(SIGGAN_E_INVALID, "null tensor");
     hipStream_t s = (hipStream_t)stream;
+    drop_dreal(c);                     // the activation rows of a D(real) forward started ahead of time are overwritten
+    if ((rc = settle(c, s))) return rc;
     repack(c, s, s, c->g_dirty, c->d_dirty);
     c->g_dirty = c->d_dirty = false;
     const bool drop = training != 0 && c->cfg.dropout > 0.f;
     if (drop) { if (!masks_dev) launch_tick(c->dev, s); make_noise(c, masks_dev, batch, 0, 1, s); }
-    c->dreal_B = 0;                    // the activation rows of a D(real) forward started ahead of time are overwritten
     d_forward_rows(c, x_dev, 0, batch, drop, s, c->slab_k);
     if (probs_dev) launch_bce(c->logits, batch, batch, 0.f, 0.f, probs_dev, nullptr, nullptr, 0, s);
-    if (features_dev) launch_cls_features(c->d_a[c->Ld], features_dev, batch, c->dC[c->Ld], s);
+    if (features_dev) launch_cls_features(c->dt, c->d_a[c->Ld], features_dev, batch, c->dC[c->Ld], s);
     LAUNCHCHK();
-    return SIGGAN_OK;
+    return lane_check(c);
 }
 
 static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
                           const siggan_hyper* hp, float* metrics_dev, void* stream, bool spec_g, const float* zg_dev) {
+    ENTER(c);
     int rc = check_call(c, batch);
     if (rc) return rc;
     if ((rc = check_hyper(hp))) return rc;
@@ -774,8 +856,11 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     // stage the caller's tensors into fixed workspace slots (captured phases must see fixed addresses)
     int pre_real = 0;                          // 1: the staged batch is this step's real batch; 2: and its D(real) forward is done
     if (!real_dev) pre_real = (c->dreal_B == B && !masks_dev) ? 2 : 1;
-    else if (real_dev != c->real_stage) HIPCHK(hipMemcpyAsync(c->real_stage, real_dev, img_bytes, hipMemcpyDeviceToDevice, s));
-    c->staged_B = c->dreal_B = 0;
+    if (pre_real == 2) c->dreal_B = 0;         // consumed: the phase waits for ev_dreal where it needs the rows
+    else drop_dreal(c);                        // D(real) is redone (explicit batch / masks): the early one is abandoned
+    if ((rc = settle(c, s))) return rc;
+    if (real_dev && real_dev != c->real_stage) HIPCHK(hipMemcpyAsync(c->real_stage, real_dev, img_bytes, hipMemcpyDeviceToDevice, s));
+    c->staged_B = 0;
     if (z_dev && z_dev != c->z) HIPCHK(hipMemcpyAsync(c->z, z_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     int64_t sumC = 0;
     for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l];
@@ -793,11 +878,14 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
 }
 
 extern "C" int siggan_stage_real(siggan_ctx* c, const float* real_dev, int32_t batch, void* stream) {
+    ENTER(c);
     int rc = check_call(c, batch);
     if (rc) return rc;
     if (!real_dev) return fail(SIGGAN_E_INVALID, "null real batch");
+    drop_dreal(c);                     // an early D(real) forward of a previously staged batch still reads real_next
+    if ((rc = settle(c, (hipStream_t)stream))) return rc;
     HIPCHK(hipMemcpyAsync(c->real_next, real_dev, (size_t)batch * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    c->staged_B = batch; c->dreal_B = 0;
+    c->staged_B = batch;
     return SIGGAN_OK;
 }
 
@@ -812,6 +900,7 @@ extern "C" int siggan_step_begin(siggan_ctx* c, const float* real_dev, int32_t b
 }
 
 static int apply_common(siggan_ctx* c, int which, const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
+    ENTER(c);
     int rc = check_call(c, 1);
     if (rc) return rc;
     if ((rc = check_hyper(hp))) return rc;
@@ -822,6 +911,7 @@ static int apply_common(siggan_ctx* c, int which, const siggan_hyper* hp, float*
     for (const float* p : need)
         if (!p) return fail(SIGGAN_E_STATE, "gradient / Adam arenas were not bound");
     hipStream_t s = (hipStream_t)stream;
+    if ((rc = settle(c, s))) return rc;
     // metrics of a step live in ONE buffer: the one the *_grads call named (its losses are already there)
     if (!metrics_dev) metrics_dev = c->metrics_last != c->metrics ? c->metrics_last : nullptr;
     else if (c->metrics_last && metrics_dev != c->metrics_last)
@@ -846,11 +936,13 @@ extern "C" int siggan_d_step(siggan_ctx* c, const float* real_dev, int32_t batch
 
 extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, const siggan_hyper* hp, float* metrics_dev,
                               void* stream) {
+    ENTER(c);
     int rc = check_call(c, batch);
     if (rc) return rc;
     if ((rc = check_hyper(hp))) return rc;
     if (!c->st.g_grads) return fail(SIGGAN_E_STATE, "gradient arena was not bound");
     hipStream_t s = (hipStream_t)stream;
+    if ((rc = settle(c, s))) return rc;
     const int B = batch;
     const bool spec = c->g_fwd_pending != 0;
     if (spec && (c->g_fwd_pending != B || z_dev))
@@ -889,7 +981,7 @@ extern "C" int siggan_g_step(siggan_ctx* c, int32_t batch, const float* z_dev, c
 // ------------------------------------------------------------------------------------------
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-extern "C" int siggan_op_conv4x4s2(siggan_ctx* c, int32_t form, const float* in_dev, const float* w_dev, float* out_dev,
+extern "C" int siggan_op_conv4x4s2(siggan_ctx* c, int32_t form, const void* in_dev, const float* w_dev, void* out_dev,
                                    int32_t batch, int32_t h_in, int32_t c_in, int32_t c_out, void* stream) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     if (!in_dev || !w_dev || !out_dev) return fail(SIGGAN_E_INVALID, "null tensor");
@@ -897,33 +989,38 @@ extern "C" int siggan_op_conv4x4s2(siggan_ctx* c, int32_t form, const float* in_
     if (!pow2(h_in) || !pow2(c_in) || !pow2(c_out) || c_in < 32 || c_out < 32 || c_in > 512 || c_out > 512 || batch < 1)
         return fail(SIGGAN_E_INVALID, "shape not in the model family (pow2 dims, 32 <= C <= 512)");
     if (form == 0 && h_in < 2) return fail(SIGGAN_E_INVALID, "down form needs h_in >= 2");
-    HIPCHK(hipSetDevice(c->cfg.device));
+    DevGuard dg_(c->cfg.device); HIPCHK(dg_.err);
     hipStream_t s = (hipStream_t)stream;
-    GConvArgs a; memset(&a, 0, sizeof a); a.slab = c->slab_k; a.slab_floats = c->slab_k_floats; a.zeros = c->zeros;
+    GConvArgs a = gconv_args(c);
     a.in = in_dev; a.wp = c->op_pack; a.out = out_dev; a.B = batch; a.Hi = h_in; a.Wi = h_in; a.Ci = c_in; a.Co = c_out;
     a.form = form; a.epi = EPI_RAW;
+    PrepTable t; t.njobs = 0; t.overflow = 0;
+    PrepJob j; memset(&j, 0, sizeof j);
+    j.src = w_dev; j.dst = (float*)c->op_pack; j.dt = c->dt;
     if (form == 0) {
-        launch_pack_down(w_dev, c->op_pack, c_out, c_in, s);
+        j.type = PREP_PACK_DOWN; j.O = c_out; j.I = c_in;
         a.Ho = a.Wo = h_in / 2; a.lgHr = a.lgWr = ilog2i(h_in / 2); a.M = batch * (h_in / 2) * (h_in / 2);
     } else {
-        launch_pack_up(w_dev, c->op_pack, c_in, c_out, s);
+        j.type = PREP_PACK_UP; j.I = c_in; j.O = c_out;
         a.Ho = a.Wo = 2 * h_in; a.lgHr = a.lgWr = ilog2i(h_in); a.M = batch * h_in * h_in;
     }
+    prep_add(t, j, (long long)c_in * c_out * 16);
+    if (!launch_prepare(t, BN_EPS, s)) return fail(SIGGAN_E_STATE, "prepare table overflow");
     launch_gconv(a, s);
     LAUNCHCHK();
     return SIGGAN_OK;
 }
 
-extern "C" int siggan_op_conv4x4s2_wgrad(siggan_ctx* c, const float* small_dev, const float* large_dev, float* dw_dev,
+extern "C" int siggan_op_conv4x4s2_wgrad(siggan_ctx* c, const void* small_dev, const void* large_dev, float* dw_dev,
                                          int32_t batch, int32_t h_small, int32_t c_small, int32_t c_large, void* stream) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     if (!small_dev || !large_dev || !dw_dev) return fail(SIGGAN_E_INVALID, "null tensor");
     if (!pow2(h_small) || !pow2(c_small) || !pow2(c_large) || c_small < 32 || c_large < 32 || c_small > 512 || c_large > 512 ||
         batch < 1)
         return fail(SIGGAN_E_INVALID, "shape not in the model family (pow2 dims, 32 <= C <= 512)");
-    HIPCHK(hipSetDevice(c->cfg.device));
+    DevGuard dg_(c->cfg.device); HIPCHK(dg_.err);
     hipStream_t s = (hipStream_t)stream;
-    WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros;
+    WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
     w.S = small_dev; w.L = large_dev; w.slab = c->slab; w.dw = dw_dev; w.B = batch; w.Cs = c_small; w.Cl = c_large;
     w.lgHs = w.lgWs = ilog2i(h_small); w.lgCl = ilog2i(c_large); w.K = batch * h_small * h_small;
     const int max_splits = (int)(c->slab_floats / ((int64_t)c_small * (16 * c_large + 1)));
@@ -939,7 +1036,7 @@ extern "C" int siggan_op_adam(siggan_ctx* c, float* p, float* g, float* m, float
     if (rc) return rc;
     if (!p || !g || !m || !v || n < 1 || step < 1) return fail(SIGGAN_E_INVALID, "bad argument");
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return fail(SIGGAN_E_INVALID, "arenas must be 16-byte aligned");
-    HIPCHK(hipSetDevice(c->cfg.device));
+    DevGuard dg_(c->cfg.device); HIPCHK(dg_.err);
     hipStream_t s = (hipStream_t)stream;
     float* steps = c->partial + ((2 << 20) - 64);          // scratch slot: step count before the increment
     const float prev = (float)(step - 1);
@@ -956,7 +1053,7 @@ extern "C" int siggan_op_adam(siggan_ctx* c, float* p, float* g, float* m, float
 static Prof g_prof_store;
 extern "C" int siggan_prof_enable(siggan_ctx* c, int32_t on) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
-    HIPCHK(hipSetDevice(c->cfg.device));
+    DevGuard dg_(c->cfg.device); HIPCHK(dg_.err);
     HIPCHK(hipDeviceSynchronize());
     g_prof_store.clear();
     g_prof = on ? &g_prof_store : nullptr;
@@ -966,7 +1063,7 @@ extern "C" int32_t siggan_prof_slots(void) { return Prof::NID - 1; }
 extern "C" int siggan_prof_read(siggan_ctx* c, int32_t idx, char* name, int32_t name_cap, int64_t* launches, double* ms,
                                 double* flops) {
     if (!c || !name || !launches || !ms || !flops || idx < 0 || idx >= Prof::NID - 1) return fail(SIGGAN_E_INVALID, "bad argument");
-    HIPCHK(hipSetDevice(c->cfg.device));
+    DevGuard dg_(c->cfg.device); HIPCHK(dg_.err);
     HIPCHK(hipDeviceSynchronize());
     snprintf(name, name_cap, "%s", Prof::name(idx));
     *launches = 0; *ms = 0.0; *flops = 0.0;
@@ -981,8 +1078,9 @@ extern "C" int siggan_prof_read(siggan_ctx* c, int32_t idx, char* name, int32_t 
 
 extern "C" int siggan_debug_tensor(siggan_ctx* c, const char* name, int32_t idx, float* out_dev, int64_t n, void* stream) {
     if (!c || !name || !out_dev || n < 1) return fail(SIGGAN_E_INVALID, "bad argument");
-    float* src = nullptr; int64_t capv = 0;
-    float** ptr = &src; int64_t* cap = &capv;
+    const void* src = nullptr; int64_t capv = 0;
+    const void** ptr = &src; int64_t* cap = &capv;
+    bool typed = true;                          // element type dt (converted to fp32 on the way out) vs. plain fp32
     const int64_t Bm = c->Bm, Bd = 2 * Bm, SS = (int64_t)c->S * c->S;
     auto gsz = [&](int l) { const int64_t H = 4 << l; return Bm * H * H * c->gC[l]; };
     auto dsz = [&](int l) { const int64_t H = c->S >> l; return Bd * H * H * c->dC[l]; };
@@ -992,17 +1090,18 @@ extern "C" int siggan_debug_tensor(siggan_ctx* c, const char* name, int32_t idx,
     else if (!strcmp(name, "g_da") && gl) { *ptr = c->g_da[idx]; *cap = gsz(idx); }
     else if (!strcmp(name, "d_a") && dl) { *ptr = c->d_a[idx]; *cap = dsz(idx); }
     else if (!strcmp(name, "d_dv") && dl) { *ptr = c->d_dv[idx]; *cap = dsz(idx); }
-    else if (!strcmp(name, "z")) { *ptr = c->z; *cap = Bm * c->latent; }
-    else if (!strcmp(name, "z_g")) { *ptr = c->z_g; *cap = Bm * c->latent; }
-    else if (!strcmp(name, "img")) { *ptr = c->img; *cap = Bm * SS; }
-    else if (!strcmp(name, "dpre")) { *ptr = c->dpre; *cap = Bm * SS; }
-    else if (!strcmp(name, "logits")) { *ptr = c->logits; *cap = Bd; }
-    else if (!strcmp(name, "probs")) { *ptr = c->probs; *cap = Bd; }
-    else if (!strcmp(name, "dlogit")) { *ptr = c->dlogit; *cap = Bd; }
+    else if (!strcmp(name, "z")) { *ptr = c->z; *cap = Bm * c->latent; typed = false; }
+    else if (!strcmp(name, "z_g")) { *ptr = c->z_g; *cap = Bm * c->latent; typed = false; }
+    else if (!strcmp(name, "img")) { *ptr = c->img; *cap = Bm * SS; typed = false; }
+    else if (!strcmp(name, "dpre")) { *ptr = c->dpre; *cap = Bm * SS; typed = false; }
+    else if (!strcmp(name, "logits")) { *ptr = c->logits; *cap = Bd; typed = false; }
+    else if (!strcmp(name, "probs")) { *ptr = c->probs; *cap = Bd; typed = false; }
+    else if (!strcmp(name, "dlogit")) { *ptr = c->dlogit; *cap = Bd; typed = false; }
     else return fail(SIGGAN_E_INVALID, "unknown debug tensor %s[%d]", name, idx);
     if (n > capv) return fail(SIGGAN_E_INVALID, "debug tensor %s[%d] holds %lld floats, %lld asked", name, idx, (long long)capv, (long long)n);
-    HIPCHK(hipSetDevice(c->cfg.device));
-    HIPCHK(hipMemcpyAsync(out_dev, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    DevGuard dg_(c->cfg.device); HIPCHK(dg_.err);
+    if (typed && c->dt != DT_F32) { launch_to_f32(c->dt, src, out_dev, n, (hipStream_t)stream); LAUNCHCHK(); }
+    else HIPCHK(hipMemcpyAsync(out_dev, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SIGGAN_OK;
 }
 
@@ -1013,7 +1112,7 @@ extern "C" int siggan_augment_batch(int32_t device, const uint8_t* cache_dev, in
     if (augment && (!params_dev || !tables_dev)) return fail(SIGGAN_E_INVALID, "augment needs params and tables");
     if (batch < 1 || n_images < 1 || size < 1 || size > 1024) return fail(SIGGAN_E_INVALID, "bad batch / cache / image size");
     if (fill < 0 || fill > 255) return fail(SIGGAN_E_INVALID, "fill must be a byte value");
-    HIPCHK(hipSetDevice(device));
+    DevGuard dg_(device); HIPCHK(dg_.err);
     launch_augment(cache_dev, n_images, index_dev, params_dev, tables_dev, lut_dev, out_dev, batch, size, augment != 0, fill, (hipStream_t)stream);
     LAUNCHCHK();
     return SIGGAN_OK;
@@ -1021,7 +1120,7 @@ extern "C" int siggan_augment_batch(int32_t device, const uint8_t* cache_dev, in
 
 extern "C" int siggan_op_randn(siggan_ctx* c, float* out_dev, int64_t n, void* stream) {
     if (!c || !out_dev || n < 1) return fail(SIGGAN_E_INVALID, "bad argument");
-    HIPCHK(hipSetDevice(c->cfg.device));
+    DevGuard dg_(c->cfg.device); HIPCHK(dg_.err);
     hipStream_t s = (hipStream_t)stream;
     launch_tick(c->dev, s);
     launch_randn(out_dev, n, c->dev, 3, s);

@@ -30,7 +30,7 @@ class Engine:
     no conversion)."""
 
     def __init__(self, latent_dim=100, image_size=64, max_batch=64, device="cuda:0", seed=0,
-                 dropout=0.25, leaky_slope=0.2, image_channels=1):
+                 dropout=0.25, leaky_slope=0.2, image_channels=1, dtype="f32", f16_grad_scale=0.0):
         layout.check_size(image_size)
         if image_channels != 1:
             raise ValueError(f"only image_channels == 1 is built, got {image_channels}")
@@ -42,7 +42,15 @@ class Engine:
         self.lib = _lib.load()
         self.latent_dim, self.image_size, self.max_batch = int(latent_dim), int(image_size), int(max_batch)
         self.dropout, self.leaky_slope, self._seed = float(dropout), float(leaky_slope), int(seed)
+        # storage type of the library-owned activations and MFMA weight copies ("f32": the reference's arithmetic and
+        # the parity path; "bf16" / "f16": 16-bit storage and MFMA operands, fp32 everything else -- BASELINE configs[2] / [4])
+        if str(dtype) not in _lib.DTYPES:
+            raise ValueError(f"dtype must be one of f32 / bf16 / f16, got {dtype!r}")
+        self.dtype = {0: "f32", 1: "bf16", 2: "f16"}[_lib.DTYPES[str(dtype)]]
+        self.act_dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[self.dtype]
+        self.f16_grad_scale = float(f16_grad_scale)
         self._h = None
+        self._staged = None
         self._create_context()
         h = self._h
         self.g_entries = layout.generator_entries(latent_dim, image_size)
@@ -70,7 +78,7 @@ class Engine:
 
     def _create_context(self):
         cfg = _lib.Config(self.device.index, self.latent_dim, self.image_size, 1, self.max_batch,
-                          self.dropout, self.leaky_slope, self._seed)
+                          self.dropout, self.leaky_slope, self._seed, _lib.DTYPES[self.dtype], self.f16_grad_scale)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.siggan_create(C.byref(cfg), C.byref(h)))
@@ -82,6 +90,7 @@ class Engine:
             self.g_bn_var, self.g_bn_batches, self.d_params, self.d_grads, self.d_exp_avg, self.d_exp_avg_sq,
             self.d_adam_steps)])
         _lib.check(self.lib.siggan_bind(self._h, C.byref(st)))
+        self._staged = None
 
     def ensure_batch(self, batch):
         """Grow the library workspace (a new context bound to the SAME arenas) when a larger batch
@@ -89,10 +98,14 @@ class Engine:
         if batch <= self.max_batch:
             return
         torch.cuda.synchronize(self.device)
+        seed, offset = self.rng_state()          # the z / dropout stream continues where the old context stood
         self.lib.siggan_destroy(self._h)
+        self._h = None
+        self._staged = None                      # a batch staged in the old context is gone
         self.max_batch = 1 << (int(batch) - 1).bit_length()
         self._create_context()
         self._bind()
+        self.seed(seed, offset)
 
     # ---- views -------------------------------------------------------------------------------
     def views(self, which, arena="params"):
@@ -137,7 +150,16 @@ class Engine:
         _lib.check(self.lib.siggan_set_mode(self._h, (1 if graph else 0) | (2 if overlap else 0)))
 
     def seed(self, seed, offset=0):
+        """(Re)position the library RNG (z, dropout tables): Philox key ``seed``, call counter ``offset`` (the counter
+        ticks once per optimiser update, i.e. twice per G+D step)."""
+        self._seed = int(seed)
         _lib.check(self.lib.siggan_seed(self._h, int(seed), int(offset)))
+
+    def rng_state(self):
+        """(seed, offset) of the library RNG as it stands (synchronises the device)."""
+        s, o = C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.siggan_rng_state(self._h, C.byref(s), C.byref(o)))
+        return int(s.value), int(o.value)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -223,11 +245,13 @@ class Engine:
             raise ValueError(f"real_images must be (B, 1, {s}, {s}), got {tuple(next_real.shape)}")
         self._check_batch(next_real.shape[0])
         _lib.check(self.lib.siggan_stage_real(self._h, _ptr(next_real), next_real.shape[0], self._stream()))
-        self._staged = (next_real.data_ptr(), next_real._version, tuple(next_real.shape))
+        # the tensor itself is kept: identity + version recognise it at the next step, and holding the reference keeps
+        # the allocator from handing its address to a different batch in between
+        self._staged = (next_real, next_real._version)
 
     def _take_staged(self, real):
-        st, self._staged = getattr(self, "_staged", None), None
-        return st is not None and st == (real.data_ptr(), real._version, tuple(real.shape))
+        st, self._staged = self._staged, None
+        return st is not None and st[0] is real and st[1] == real._version
 
     def step_begin(self, real, z=None, masks=None, z_g=None, label_smoothing=0.9):
         """d_compute_grads + the following G step's training forward on its own lane (pipelined
@@ -291,11 +315,14 @@ class Engine:
 
     # ---- operator-level calls (tests / profiling) --------------------------------------------------
     def op_conv4x4s2(self, form, x_nhwc, w):
+        """Activations in / out in the context's element type (``act_dtype``: the input is cast, i.e. rounded to
+        nearest, if it is not already); weights fp32 in the torch layout."""
         b, h, _, cin = x_nhwc.shape
         cout = w.shape[0] if form == 0 else w.shape[1]
         ho = h // 2 if form == 0 else 2 * h
-        out = torch.empty(b, ho, ho, cout, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.siggan_op_conv4x4s2(self._h, form, _ptr(x_nhwc.contiguous()), _ptr(w.contiguous()), _ptr(out),
+        x = x_nhwc.to(self.act_dtype).contiguous()
+        out = torch.empty(b, ho, ho, cout, dtype=self.act_dtype, device=self.device)
+        _lib.check(self.lib.siggan_op_conv4x4s2(self._h, form, _ptr(x), _ptr(w.float().contiguous()), _ptr(out),
                                                 b, h, cin, cout, self._stream()))
         return out
 
@@ -303,8 +330,8 @@ class Engine:
         b, hs, _, cs = small_nhwc.shape
         cl = large_nhwc.shape[3]
         dw = torch.empty(cs, cl, 4, 4, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.siggan_op_conv4x4s2_wgrad(self._h, _ptr(small_nhwc.contiguous()), _ptr(large_nhwc.contiguous()),
-                                                      _ptr(dw), b, hs, cs, cl, self._stream()))
+        sm, lg = small_nhwc.to(self.act_dtype).contiguous(), large_nhwc.to(self.act_dtype).contiguous()
+        _lib.check(self.lib.siggan_op_conv4x4s2_wgrad(self._h, _ptr(sm), _ptr(lg), _ptr(dw), b, hs, cs, cl, self._stream()))
         return dw
 
     def op_adam(self, p, g, m, v, step, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8, clip=None, grad_scale=1.0):
@@ -341,6 +368,7 @@ class Engine:
         return out.view(shape)
 
     def close(self):
+        self._staged = None
         if getattr(self, "_h", None):
             self.lib.siggan_destroy(self._h)
             self._h = None

@@ -246,6 +246,10 @@ class GANTrainer:
         self.model.d_optimizer.load_state_dict(ck["d_optimizer_state_dict"])
         self.start_epoch = ck["epoch"] + 1
         self.global_step = ck["global_step"]
+        # a resumed run must not replay the z / dropout draws of steps 0..N: position the library RNG behind them
+        # (one tick per optimiser update = n_critic + 1 per batch)
+        eng = self.model.engine
+        eng.seed(eng._seed, offset=(int(getattr(self.config, "n_critic", 1)) + 1) * int(self.global_step))
         self.best_g_loss = ck.get("best_g_loss", float("inf"))
         if "fixed_noise" in ck:
             self.fixed_noise = ck["fixed_noise"].to(self.model.device)

@@ -47,7 +47,7 @@ class VanillaGAN(nn.Module):
     def __init__(self, latent_dim: int = 100, image_size: int = 64, image_channels: int = 1, g_lr: float = 2e-4,
                  d_lr: float = 2e-4, beta1: float = 0.5, beta2: float = 0.999, label_smoothing: float = 0.9,
                  use_spectral_norm: bool = False, device: Optional[str] = None, max_batch: int = 64,
-                 seed: int = 0) -> None:
+                 seed: Optional[int] = None) -> None:
         super().__init__()
         self.latent_dim, self.image_size, self.image_channels = latent_dim, image_size, image_channels
         self.g_lr, self.d_lr, self.beta1, self.beta2 = g_lr, d_lr, beta1, beta2
@@ -62,6 +62,10 @@ class VanillaGAN(nn.Module):
             raise RuntimeError("VanillaGAN (HIP engine) needs a ROCm device; there is no CPU path")
         if self._device.index is None:
             self._device = torch.device("cuda", torch.cuda.current_device())
+        if seed is None:
+            # the reference draws z / dropout from torch's global generator (never seeded by the trainer): follow
+            # whatever seed that generator was given (torch.manual_seed, or the per-process random default)
+            seed = torch.initial_seed() & ((1 << 63) - 1)
         self.engine = Engine(latent_dim=latent_dim, image_size=image_size, max_batch=max_batch,
                              device=str(self._device), seed=seed, image_channels=image_channels)
         self.generator = Generator(latent_dim=latent_dim, output_size=image_size, output_channels=image_channels,
@@ -209,6 +213,8 @@ class VanillaGAN(nn.Module):
         self.discriminator.load_state_dict(ck["discriminator_state_dict"])
         self.current_epoch = ck.get("current_epoch", 0)
         self.global_step = ck.get("global_step", 0)
+        # continue the z / dropout stream behind the steps already taken (the counter ticks once per optimiser update)
+        self.engine.seed(self.engine._seed, offset=2 * int(self.global_step))
         if load_optimizer and "g_optimizer_state_dict" in ck:
             self.g_optimizer.load_state_dict(ck["g_optimizer_state_dict"])
             self.d_optimizer.load_state_dict(ck["d_optimizer_state_dict"])

@@ -33,8 +33,8 @@ def load_engine_state(eng, size, latent, warm):
     return eng
 
 
-def make_engine(size, latent, max_batch, warm=False, seed=0):
-    eng = Engine(latent_dim=latent, image_size=size, max_batch=max_batch, device="cuda:0", seed=seed)
+def make_engine(size, latent, max_batch, warm=False, seed=0, dtype="f32"):
+    eng = Engine(latent_dim=latent, image_size=size, max_batch=max_batch, device="cuda:0", seed=seed, dtype=dtype)
     return load_engine_state(eng, size, latent, warm)
 
 

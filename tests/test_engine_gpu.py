@@ -261,3 +261,49 @@ def test_latent_drawn_inside_the_fc_kernel():
     for a, b in zip((e1.g_params, e1.g_exp_avg_sq, e1.g_bn_mean), (e2.g_params, e2.g_exp_avg_sq, e2.g_bn_mean)):
         assert torch.equal(a, b)
     e1.close(); e2.close()
+
+
+def test_abandoned_staged_forward_is_ordered():
+    """A D(real) forward started ahead of time (siggan_stage_real) that no D step consumes must not race with what
+    follows: a Discriminator forward on other images right behind the step, then a step on a DIFFERENT batch, give
+    exactly what the un-staged sequence gives (the abandoned lane is waited for before its rows / packs are reused)."""
+    from hipcommon import cuda, make_engine
+    size, latent, batch = 64, 100, 16
+    reals = [cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"] + 3 * t))) for t in range(3)]
+    probe_x = cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"] + 99)))
+
+    def run(staged):
+        eng = make_engine(size, latent, batch, warm=True)
+        eng.seed(77)
+        out = [eng.train_step(reals[0], clip=0.5, next_real=reals[1] if staged else None)]
+        out.append(eng.d_forward(probe_x, training=False).clone())       # abandons the forward of reals[1]
+        out.append(eng.train_step(reals[2], clip=0.5, next_real=reals[1] if staged else None))
+        other = reals[0].clone()                                          # a different tensor: the staged one is dropped
+        out.append(eng.train_step(other, clip=0.5))
+        state = [x.clone() for x in (eng.g_params, eng.d_params, eng.d_exp_avg_sq, eng.g_bn_var)]
+        eng.close()
+        return out, state
+
+    (m0, p0, m1, m2), s0 = run(False)
+    (n0, q0, n1, n2), s1 = run(True)
+    assert m0 == n0 and m1 == n1 and m2 == n2
+    assert torch.equal(p0, q0)
+    for a, b in zip(s0, s1):
+        assert torch.equal(a, b)
+
+
+def test_rng_position_survives_a_larger_batch_and_is_readable():
+    """Engine.ensure_batch re-creates the context for a larger batch: the z / dropout stream must continue (same seed,
+    same call counter), not rewind to step 0."""
+    from hipcommon import cuda, make_engine
+    size, latent, batch = 64, 100, 8
+    real = cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"])))
+    eng = make_engine(size, latent, batch, warm=True)
+    eng.seed(4321)
+    eng.train_step(real)
+    eng.train_step(real)
+    seed, off = eng.rng_state()
+    assert seed == 4321 and off == 4                    # one tick per optimiser update
+    eng.g_forward(torch.zeros(2 * batch, latent, device="cuda:0"))      # grows the workspace
+    assert eng.max_batch == 2 * batch and eng.rng_state() == (4321, 4)
+    eng.close()

@@ -94,3 +94,78 @@ def test_randn_moments(eng):
     assert abs((x ** 4).mean().item() - 3) < 0.1
     assert (x - y).abs().max().item() > 1.0, "successive calls must differ"
     assert torch.isfinite(x).all()
+
+
+# ---- 16-bit operand kernels (bf16 / f16 storage + MFMA operands, fp32 accumulate; BASELINE configs[2] / [4]) --------------
+# The check is exact up to fp32 accumulation order: the CPU evaluates the same op in fp32 on the inputs ROUNDED to the
+# narrow type (what the kernel reads).  Weight gradients are fp32 results (rtol 2e-4 of scale, as for the fp32 kernels);
+# conv outputs are stored in the narrow type, so each element additionally carries one rounding of the output (half an ulp:
+# 2^-9 relative for bf16, 2^-12 for f16).
+NARROW = {"bf16": (torch.bfloat16, 2.0 ** -8), "f16": (torch.float16, 2.0 ** -11)}
+
+
+@pytest.fixture(scope="module", params=["bf16", "f16"])
+def eng16(request):
+    from hipcommon import Engine
+    e = Engine(latent_dim=100, image_size=64, max_batch=8, device="cuda:0", seed=1, dtype=request.param)
+    yield e
+    e.close()
+
+
+def _close16(got, want, ulp, what):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    scale = want.abs().max().item() + 1e-30
+    tol = ulp * want.abs() + 2e-4 * scale
+    bad = (got - want).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements off, worst {(got - want).abs().max().item():.3e} (scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("b,h,ci,co", DOWN)
+def test_conv_down_16(eng16, b, h, ci, co):
+    td, ulp = NARROW[eng16.dtype]
+    g = torch.Generator().manual_seed(b * 1000 + h + ci + co)
+    x = torch.randn(b, ci, h, h, generator=g).to(td).float()
+    w = (torch.randn(co, ci, 4, 4, generator=g) * 0.05)
+    want = F.conv2d(x, w.to(td).float(), None, stride=2, padding=1)
+    got = eng16.op_conv4x4s2(0, x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda())
+    assert got.dtype == td
+    _close16(got.float().permute(0, 3, 1, 2), want, ulp, f"down {eng16.dtype}")
+
+
+@pytest.mark.parametrize("b,h,ci,co", UP)
+def test_conv_up_16(eng16, b, h, ci, co):
+    td, ulp = NARROW[eng16.dtype]
+    g = torch.Generator().manual_seed(b * 1000 + h + ci + co + 7)
+    x = torch.randn(b, ci, h, h, generator=g).to(td).float()
+    w = (torch.randn(ci, co, 4, 4, generator=g) * 0.05)
+    want = F.conv_transpose2d(x, w.to(td).float(), None, stride=2, padding=1)
+    got = eng16.op_conv4x4s2(1, x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda())
+    _close16(got.float().permute(0, 3, 1, 2), want, ulp, f"up {eng16.dtype}")
+
+
+@pytest.mark.parametrize("b,hs,cs,cl", [(2, 16, 128, 64), (3, 8, 256, 128), (2, 4, 512, 256), (2, 16, 64, 32), (1, 32, 32, 32),
+                                        (1, 4, 512, 512), (64, 16, 128, 64), (1, 4, 32, 32), (5, 8, 64, 32)])
+def test_conv_wgrad_16(eng16, b, hs, cs, cl):
+    td, _ = NARROW[eng16.dtype]
+    g = torch.Generator().manual_seed(b + hs + cs + cl)
+    small = torch.randn(b, cs, hs, hs, generator=g).to(td).float()
+    large = torch.randn(b, cl, 2 * hs, 2 * hs, generator=g).to(td).float()
+    w = torch.zeros(cs, cl, 4, 4, requires_grad=True)
+    (F.conv2d(large, w, None, stride=2, padding=1) * small).sum().backward()
+    got = eng16.op_wgrad(small.permute(0, 2, 3, 1).contiguous().cuda(), large.permute(0, 2, 3, 1).contiguous().cuda())
+    assert got.dtype == torch.float32
+    _close(got, w.grad, what=f"wgrad {eng16.dtype}")
+
+
+def test_wgrad_16_fragment_map_exact(eng16):
+    """Exact-integer data with an asymmetric pattern: a wrong lane <-> element map of the transposing LDS reads (or a
+    swapped operand) cannot produce the right integers."""
+    b, hs, cs, cl = 1, 8, 64, 32
+    n = torch.arange(b * hs * hs * cs, dtype=torch.float32)
+    small = ((n * 7 + 3) % 5 - 2).view(b, hs, hs, cs)                      # values in {-2..2}, NHWC
+    m = torch.arange(b * 4 * hs * hs * cl, dtype=torch.float32)
+    large = ((m * 11 + 1) % 7 - 3).view(b, 2 * hs, 2 * hs, cl)             # values in {-3..3}
+    w = torch.zeros(cs, cl, 4, 4, requires_grad=True)
+    (F.conv2d(large.permute(0, 3, 1, 2), w, None, stride=2, padding=1) * small.permute(0, 3, 1, 2)).sum().backward()
+    got = eng16.op_wgrad(small.cuda(), large.cuda())
+    assert torch.equal(got.cpu(), w.grad)
