@@ -1,39 +1,58 @@
 #!/usr/bin/env python3
 """Headline benchmark: signature images/sec for one G+D train step (n_critic = 1).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--dtype f32|bf16|f16] [--size 64|128] [--batch B] [--latent Z]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): reference conv G/D, 64x64x1, z = 100, batch 64 PER GPU, fp32,
-dropout 0.25 active in the D step, label smoothing 0.9, Adam lr 2e-4 betas (0.5, 0.999), clipping
-off; the real batch is synthetic U[-1,1] resident in HBM, z and the dropout masks are drawn by the
-library's RNG inside the step, weights are random-init from the reference's init distribution.
-A "step" = siggan_d_grads/apply + siggan_g_grads/apply through the C ABI (with N > 1 the two flat
-gradient buckets are all-reduced over RCCL between grads and apply: weak scaling, per-replica BN).
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on): reference conv G/D, 64x64x1,
+z = 100, batch 64 PER GPU, fp32, dropout 0.25 active in the D step, label smoothing 0.9, Adam lr 2e-4 betas (0.5, 0.999),
+clipping off; the real batch is synthetic U[-1,1] resident in HBM, z and the dropout masks are drawn by the library's RNG
+inside the step, weights are random-init from the reference's init distribution.  The other flags select the per-GPU
+workloads of the other BASELINE configs (tracked lines under profiles/, not the driver's line): --batch 128 (configs[3]),
+--dtype bf16 (configs[2]: bf16 storage / MFMA operands, fp32 masters), --size 128 --latent 128 --batch 32 --dtype f16
+(configs[4]).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the dominant MFMA kernel: algorithmic FLOPs per launch / its mean launch duration
-                  measured with HIP events on the launch stream over a second, instrumented pass of
-                  the same K steps, run one kernel at a time (the timed pass carries no instrumentation
-                  and overlaps independent kernels on side streams; `--serialize` turns that off for the
-                  whole run, which is how the rocprofv3 summaries under profiles/ are taken)
+A "step" = siggan_step_begin / d_apply / g_grads / g_apply through the C ABI.  With N > 1 every rank runs the step on its
+own shard (weak scaling, per-replica BatchNorm) and the two flat gradient buckets are sum-all-reduced over RCCL INSIDE the
+library (siggan_comm_init; torch.distributed only carries the 128-byte id and the timing barrier).
+
+Timing: W warm-up steps, then `--blocks` (default 10) blocks of EXACTLY K steps, each bracketed by a barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `ms_per_step` / `value` are the MEDIAN block, p10 / p90
+and the first block are reported beside it.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with:
+  roofline     -- the dominant MFMA kernel: algorithmic FLOPs per launch / its mean launch duration, measured live with HIP
+                  events stamped by the launch itself (hipExtLaunchKernelGGL) over a second, instrumented pass of K steps run
+                  one kernel at a time; `peak` is derived from the device (compute units x clock x FLOP/clk/CU of the dtype's
+                  MFMA); `hbm` gives the same kernel's algorithmic bytes / duration against 8 TB/s.  `traffic` (HBM bytes per
+                  launch from PMC counters) comes from a committed rocprofv3 pass and is labelled with its file
   cpu_baseline -- the oracle's same step (torch CPU, fp32) timed on the host cores (rank 0, N = 1)
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SIZE, LATENT, BATCH = 64, 100, 64
-FLOP_PER_IMAGE = 1975.8e6          # 8*D_fwd + 4*G_fwd, SURVEY 8(d) (conv/convT/linear MACs x 2)
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+# algorithmic work per image per G+D step: 8*D_fwd + 4*G_fwd (conv / convT / linear MACs x 2), SURVEY 8(d)
+FLOP_PER_IMAGE = {(64, 100): 1975.8e6, (128, 128): 9240.2e6}
+FLOP_PER_CLK_PER_CU = {"f32": 256, "bf16": 4096, "f16": 4096}   # MI355X_MICROARCH.md: 64 (f32) / 1024 (16-bit) FLOP/clk/SIMD x 4
+HBM_PEAK_GBPS = 8000.0                                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
-def cpu_baseline(threads, budget_s=12.0):
+def flop_per_image(size, latent):
+    if (size, latent) in FLOP_PER_IMAGE:
+        return FLOP_PER_IMAGE[(size, latent)]
+    base = FLOP_PER_IMAGE[(64, 100)] if size == 64 else FLOP_PER_IMAGE[(128, 128)]
+    z0, feat = (100, 4096) if size == 64 else (128, 8192)
+    return base + 4 * 2 * feat * (latent - z0)                  # only the fc GEMM depends on the latent size (4 x G_fwd)
+
+
+def cpu_baseline(threads, size, latent, batch, budget_s=12.0):
     """The oracle (kind "port") on the host cores: same step, same shapes, fp32."""
     import torch
     for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
@@ -41,16 +60,16 @@ def cpu_baseline(threads, budget_s=12.0):
             sys.path.insert(0, p)
     from common import I, O, oracle_states
     torch.set_num_threads(threads)
-    g_sd, d_sd, g_opt, d_opt = oracle_states(SIZE, LATENT, warm=False)
-    real = torch.from_numpy(I.gen_real(BATCH, SIZE, 22))
-    chans = list(O.D_CHAIN[SIZE])
+    g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=False)
+    real = torch.from_numpy(I.gen_real(batch, size, 22))
+    chans = list(O.D_CHAIN[size])
     gen = torch.Generator().manual_seed(3)
 
     def one():
-        z1, z2 = torch.randn(BATCH, LATENT, generator=gen), torch.randn(BATCH, LATENT, generator=gen)
-        masks = [(torch.rand(BATCH, c, generator=gen) < 0.75).float() for c in chans * 2]
-        O.d_step(g_sd, d_sd, d_opt, real, z1, masks[:len(chans)], masks[len(chans):], SIZE)
-        O.g_step(g_sd, d_sd, g_opt, z2, SIZE)
+        z1, z2 = torch.randn(batch, latent, generator=gen), torch.randn(batch, latent, generator=gen)
+        masks = [(torch.rand(batch, c, generator=gen) < 0.75).float() for c in chans * 2]
+        O.d_step(g_sd, d_sd, d_opt, real, z1, masks[:len(chans)], masks[len(chans):], size)
+        O.g_step(g_sd, d_sd, g_opt, z2, size)
 
     one(); one()
     n, t0 = 0, time.perf_counter()
@@ -59,7 +78,12 @@ def cpu_baseline(threads, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 64:
             break
-    return BATCH * n / dt, n
+    return batch * n / dt, n
+
+
+def pct(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
 
 
 def main():
@@ -67,12 +91,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--blocks", type=int, default=10, help="timed blocks of --steps steps (median / p10 / p90 over them)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
+    ap.add_argument("--size", type=int, default=64, choices=[64, 128])
+    ap.add_argument("--latent", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=64, help="batch PER GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented pass")
     ap.add_argument("--serialize", action="store_true",
                     help="run every pass with side-lane overlap OFF (one kernel at a time): the mode the roofline "
                          "pass always uses, and the one to profile with rocprofv3 so per-kernel durations agree")
+    ap.add_argument("--dist", action="store_true",
+                    help="initialise torch.distributed (nccl) and the library's RCCL communicator even at world size 1")
+    ap.add_argument("--host-allreduce", action="store_true",
+                    help="N > 1: reduce the gradient buckets with torch.distributed between the step halves instead of the "
+                         "library's own communicator (fallback / comparison)")
     args = ap.parse_args()
+    size, batch, dtype = args.size, args.batch, args.dtype
+    latent = args.latent if args.latent is not None else (100 if size == 64 else 128)
 
     import torch
     import torch.distributed as dist
@@ -81,11 +117,12 @@ def main():
     from signature_gan_amd.engine import Engine
 
     rank, world, local = env_rank()
-    if args.gpus > 1 or world > 1:
+    grouped = args.gpus > 1 or world > 1 or args.dist
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         # SIGGAN_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks then
-        # share devices round-robin; RCCL itself refuses two ranks on one GPU).  The driver's runs use nccl = RCCL.
+        # share devices round-robin and the buckets go through torch.distributed; RCCL refuses two ranks on one GPU).
         backend = os.environ.get("SIGGAN_DIST_BACKEND", "nccl")
         local = local % torch.cuda.device_count() if backend != "nccl" else local
         torch.cuda.set_device(local)
@@ -93,23 +130,25 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+            args.host_allreduce = True
     else:
         torch.cuda.set_device(0)
         local = 0
     dev = torch.device("cuda", local)
 
-    eng = Engine(latent_dim=LATENT, image_size=SIZE, max_batch=BATCH, device=str(dev), seed=2 + rank)
+    eng = Engine(latent_dim=latent, image_size=size, max_batch=batch, device=str(dev), seed=2 + rank, dtype=dtype)
     eng.init_reference(seed=0)                                  # identical initial weights on every rank
     if args.serialize:
         eng.set_mode(graph=False, overlap=False)
-    dp = DataParallelStep(eng)
+    transport = "host" if (args.host_allreduce or not grouped) else "lib"
+    dp = DataParallelStep(eng, transport=transport)
     dp.sync_initial_state()
     gen = torch.Generator(device="cpu").manual_seed(1 + rank)
-    real = (torch.rand(BATCH, 1, SIZE, SIZE, generator=gen) * 2 - 1).to(dev)
+    real = (torch.rand(batch, 1, size, size, generator=gen) * 2 - 1).to(dev)
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -118,18 +157,26 @@ def main():
     # Every step still does one D(real) forward -- for its successor instead of for itself.
     for _ in range(args.warmup):
         dp.step(real, next_real=real)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        dp.step(real, next_real=real)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    block_s = []
+    for _ in range(max(1, args.blocks)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dp.step(real, next_real=real)
+        barrier()
+        dt = time.perf_counter() - t0
+        if grouped and world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        block_s.append(dt)
+    dt = statistics.median(block_s)
     m = eng.metrics.cpu()
     assert torch.isfinite(m).all(), "non-finite training metrics"
+
+    cus, khz, hbm_bytes = Engine.device_info(local)
+    peak = cus * khz * 1e3 * FLOP_PER_CLK_PER_CU[dtype] / 1e12          # TFLOP/s, dense, for this dtype's MFMA
+    fpi = flop_per_image(size, latent)
 
     roofline = None
     if rank == 0 and not args.no_roofline:
@@ -138,32 +185,46 @@ def main():
         eng.set_mode(graph=False, overlap=False)
         eng.prof_enable(True)
         for _ in range(args.steps):
-            dp.step(real, next_real=real) if world == 1 else (eng.d_step(real, sync=False), eng.g_step(BATCH, sync=False))
+            if world == 1:
+                dp.step(real, next_real=real)
+            else:
+                eng.d_compute_grads(real); eng.g_compute_grads(batch)       # local kernels only: no collective on one rank alone
         recs = eng.prof_read()
         eng.prof_enable(False)
         eng.set_mode(graph=False, overlap=not args.serialize)
         top = max(recs, key=lambda r: r["ms"])
         ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
-        traffic = None                  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
+        gbps = top["bytes"] / (top["ms"] * 1e-3) / 1e9
+        traffic, traffic_src = None, None      # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
+        tag = "" if (dtype, size, batch) == ("f32", 64, 64) else f"_{dtype}_s{size}_b{batch}"
+        tfile = os.path.join("profiles", f"r02_pmc_traffic{tag}.json")
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["per_launch_bytes"][top["name"]]["total"]
+            with open(os.path.join(ROOT, tfile)) as f:
+                tj = json.load(f)
+            traffic = tj["per_launch_bytes"][top["name"]]["total"]
+            traffic_src = {"file": tfile, "commit": tj.get("commit"), "note": "separate rocprofv3 --pmc passes of this workload, "
+                           "FETCH_SIZE doubled per MI355X_MICROARCH.md; not measured in this run"}
         except (OSError, KeyError, ValueError):
             pass
         fam_ms, fam_fl = sum(r["ms"] for r in recs), sum(r["flops"] for r in recs)
         roofline = {
-            "bound": "mfma", "kernel": top["name"], "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "bound": "mfma", "kernel": top["name"] + ("" if dtype == "f32" else f" [{dtype} operands]"),
+            "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "peak_from": {"compute_units": cus, "clock_mhz": khz / 1e3, "flop_per_clk_per_cu": FLOP_PER_CLK_PER_CU[dtype]},
+            "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": top["launches"] / args.steps,
             "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
             "gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 4),
+            "hbm": {"algorithmic_mb_per_launch": round(top["bytes"] / top["launches"] / 1e6, 3), "achieved": round(gbps, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)},
             "mfma_family": {"ms_per_step": round(fam_ms / args.steps, 4),
                             "achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 3),
                             "kernels": {r["name"]: {"launches_per_step": r["launches"] / args.steps,
                                                     "ms_per_step": round(r["ms"] / args.steps, 4),
-                                                    "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)} for r in recs}},
+                                                    "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                                                    "algorithmic_gbps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in recs}},
         }
-    if world > 1:
+    if grouped:
         dist.barrier()
 
     cpu = None
@@ -172,30 +233,40 @@ def main():
         # 8): the faster one is the baseline, the other is quoted in `sample`
         runs = []
         for threads in sorted({min(16, os.cpu_count() or 1), min(8, os.cpu_count() or 1)}, reverse=True):
-            v, n = cpu_baseline(threads, budget_s=10.0)
+            v, n = cpu_baseline(threads, size, latent, batch, budget_s=10.0)
             runs.append((v, threads, n))
         (v, threads, n), rest = max(runs), [r for r in runs if r != max(runs)]
         other = "; ".join(f"{round(r[0], 1)} images/s with {r[1]} threads ({r[2]} steps)" for r in rest)
         cpu = {"value": round(v, 1), "unit": "images/s", "cores": threads, "kind": "port",
-               "sample": f"{n} G+D steps of the same workload (batch {BATCH}, 64x64, fp32) by oracle/siggan_oracle.py "
+               "sample": f"{n} G+D steps of the same workload (batch {batch}, {size}x{size}, fp32) by oracle/siggan_oracle.py "
                          f"on torch CPU with {threads} threads" + (f"; {other}" if other else "")}
 
     if rank == 0:
-        imgs = BATCH * world * args.steps
+        imgs = batch * world * args.steps
+        cfg_name = {("f32", 64, 64): "configs[1]", ("f32", 64, 128): "configs[3]", ("bf16", 64, 64): "configs[2] per-GPU shard",
+                    ("f16", 128, 32): "configs[4] per-GPU shard"}.get((dtype, size, batch), "custom")
         out = {
-            "metric": "signature images/sec (G+D train step, bs64 64x64 z=100)",
+            "metric": f"signature images/sec (G+D train step, bs{batch} {size}x{size} z={latent})",
             "value": round(imgs / dt, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: reference conv G/D 64x64x1, z=100, batch 64 per GPU, fp32, n_critic=1",
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}"},
-            "achieved_tflops_whole_step": round(imgs / dt * FLOP_PER_IMAGE / 1e12, 3),
-            "frac_of_fp32_mfma_peak_whole_step": round(imgs / dt * FLOP_PER_IMAGE / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{cfg_name}: reference conv G/D {size}x{size}x1, z={latent}, batch {batch} per GPU, {dtype}, n_critic=1",
+                       "global_batch": batch * world, "parallelism": f"dp{world}",
+                       "gradient_allreduce": None if world == 1 and not grouped else
+                       ("library RCCL (siggan_comm_init)" if transport == "lib" else "torch.distributed between the step halves")},
+            "timing": {"blocks": len(block_s), "steps_per_block": args.steps, "stat": "median",
+                       "ms_per_step_p10": round(1e3 * pct(block_s, 0.1) / args.steps, 4),
+                       "ms_per_step_p90": round(1e3 * pct(block_s, 0.9) / args.steps, 4),
+                       "ms_per_step_first_block": round(1e3 * block_s[0] / args.steps, 4)},
+            "achieved_tflops_whole_step": round(imgs / dt * fpi / 1e12, 3),
+            "frac_of_mfma_peak_whole_step": round(imgs / dt * fpi / 1e12 / (peak * world), 4),
             "final_metrics": {"d_loss": round(float(m[0]), 4), "g_loss": round(float(m[8]), 4)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if dtype == "f32":
+            out["frac_of_fp32_mfma_peak_whole_step"] = out["frac_of_mfma_peak_whole_step"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     eng.close()
 

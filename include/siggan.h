@@ -168,9 +168,29 @@ int siggan_d_step(siggan_ctx *ctx, const float *real_dev, int32_t batch, const f
 int siggan_g_step(siggan_ctx *ctx, int32_t batch, const float *z_dev, const siggan_hyper *hp,
                   float *metrics_dev, float *metrics_host, void *stream);
 
-/* data-parallel halves: *_grads leaves the local gradient in the bound *_grads arena (and the
- * forward metrics in metrics_dev); the host all-reduces the arena; *_apply scales by
- * hp->grad_scale, clips and runs Adam. */
+/* ---- data parallelism: one process per GPU, per-replica BatchNorm, ONE sum all-reduce of the flat
+ * gradient bucket per network per step over RCCL (xGMI), issued INSIDE siggan_d_apply / siggan_g_apply -- hence inside
+ * siggan_d_step / siggan_g_step -- once a communicator exists.  The reference is single-process (no torch.distributed
+ * anywhere); this is the definition SURVEY 8(e) fixes: every rank runs the reference's step (train_vanilla_gan_signatures.py:
+ * 281-376) on its contiguous shard of the global batch, gradients are averaged (the optimiser multiplies the summed bucket by
+ * grad_scale / world), clipping acts on the averaged gradient, metrics stay per rank.
+ *   siggan_comm_unique_id  rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any channel the
+ *                          launcher has (a file, MPI, a TCP store; the Python shim uses torch.distributed's store once)
+ *   siggan_comm_init       every rank, same id: ncclCommInitRank on the context's device.  world == 1 is allowed (the
+ *                          all-reduce then runs and changes nothing) -- used by the single-GPU tests
+ *   siggan_comm_broadcast  root's bytes to every rank (initial parameters / optimiser state), in place
+ * RCCL is resolved at run time from the copy the process already holds (torch's), see siggan.hip; the library owns the
+ * communicator and destroys it with the context.  Not available under SIGGAN_MODE_GRAPH. */
+#define SIGGAN_COMM_ID_BYTES 128
+int siggan_comm_unique_id(void *id_out);
+int siggan_comm_init(siggan_ctx *ctx, int32_t rank, int32_t world, const void *id);
+int siggan_comm_destroy(siggan_ctx *ctx);
+int32_t siggan_comm_world(const siggan_ctx *ctx);   /* 1 without a communicator */
+int siggan_comm_broadcast(siggan_ctx *ctx, void *buf_dev, int64_t bytes, int32_t root, void *stream);
+
+/* step halves: *_grads leaves the local gradient in the bound *_grads arena (and the forward metrics in metrics_dev);
+ * *_apply (all-reduces the arena when a communicator exists, then) scales by hp->grad_scale (/ world), clips and runs
+ * Adam.  Without a communicator a caller may reduce the arena itself between the halves (the gloo tests do). */
 int siggan_d_grads(siggan_ctx *ctx, const float *real_dev, int32_t batch, const float *z_dev,
                    const float *masks_dev, const siggan_hyper *hp, float *metrics_dev, void *stream);
 /* siggan_d_grads that ALSO enqueues the following G step's training forward (z: zg_dev, or the library
@@ -234,14 +254,17 @@ int siggan_augment_batch(int32_t device, const uint8_t *cache_dev, int64_t n_ima
                          const int32_t *params_dev, const int16_t *tables_dev, const float *lut_dev,
                          float *out_dev, int32_t batch, int32_t size, int32_t augment, int32_t fill,
                          void *stream);
+/* what the roofline peaks are derived from (bench.py): compute units x shader clock (kHz) of the device, and its HBM size */
+int siggan_device_info(int32_t device, int32_t *compute_units, int32_t *clock_khz, int64_t *hbm_bytes);
 /* measurement hook (bench.py roofline leg): while enabled, every MFMA implicit-GEMM launch is
  * bracketed by HIP events on the stream it is launched on.  siggan_prof_read synchronises the
  * device and returns, for kernel slot idx (0..siggan_prof_slots()-1): its name, launch count,
- * summed device time (ms) and summed algorithmic FLOPs. */
+ * summed device time (ms), summed algorithmic FLOPs and summed algorithmic HBM bytes (operands read once + result
+ * written once, in the context's element type). */
 int siggan_prof_enable(siggan_ctx *ctx, int32_t on);
 int32_t siggan_prof_slots(void);
 int siggan_prof_read(siggan_ctx *ctx, int32_t idx, char *name, int32_t name_cap, int64_t *launches,
-                     double *ms, double *flops);
+                     double *ms, double *flops, double *bytes);
 
 /* test hook: copy the first n elements of a library-owned workspace tensor (NHWC), converted to fp32, into out_dev:
  * "g_y"/"g_a"/"g_da" (layer 0..Lg), "d_a"/"d_dv" (block 1..Ld), "img", "dpre", "logits",

@@ -70,9 +70,16 @@ _SIGNATURES = {
     "siggan_op_adam": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, C.POINTER(Hyper), _P]),
     "siggan_op_randn": (C.c_int, [_P, _P, _I64, _P]),
     "siggan_augment_batch": (C.c_int, [_I32, _P, _I64, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "siggan_comm_unique_id": (C.c_int, [_P]),
+    "siggan_comm_init": (C.c_int, [_P, _I32, _I32, _P]),
+    "siggan_comm_destroy": (C.c_int, [_P]),
+    "siggan_comm_world": (_I32, [_P]),
+    "siggan_comm_broadcast": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "siggan_device_info": (C.c_int, [_I32, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I64)]),
     "siggan_prof_enable": (C.c_int, [_P, _I32]),
     "siggan_prof_slots": (_I32, []),
-    "siggan_prof_read": (C.c_int, [_P, _I32, C.c_char_p, _I32, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "siggan_prof_read": (C.c_int, [_P, _I32, C.c_char_p, _I32, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]),
     "siggan_debug_tensor": (C.c_int, [_P, C.c_char_p, _I32, _P, _I64, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)

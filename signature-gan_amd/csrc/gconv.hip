@@ -423,8 +423,8 @@ const char* Prof::name(int id) {
 // kernel's own begin / end (the dispatch's completion-signal timestamps), so a record's elapsed time
 // is the kernel duration rocprofv3 reports -- not the launch-to-launch gap a plain
 // hipEventRecord pair would include.
-void Prof::begin(int id, double flops, hipStream_t) {
-    Rec r; r.id = id; r.flops = flops;
+void Prof::begin(int id, double flops, double bytes, hipStream_t) {
+    Rec r; r.id = id; r.flops = flops; r.bytes = bytes;
     (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
     recs.push_back(r);
 }
@@ -433,13 +433,25 @@ void Prof::clear() {
     recs.clear();
 }
 
+// algorithmic HBM bytes of one implicit-GEMM launch: input tensor and packed weights read once, output written once
+// (+ the stored activation the fused LeakyReLU-backward epilogue reads); split-K slabs and tile re-reads are not counted
+static double gconv_bytes(const GConvArgs& a) {
+    const double es = (double)dt_size(a.dt);
+    const double in = (double)a.B * a.Hi * a.Wi * a.Ci, out = (double)a.B * a.Ho * a.Wo * a.Co, w = 16.0 * a.Ci * a.Co;
+    return es * (in + w + out * (a.epi == EPI_LRELU_BWD ? 2.0 : 1.0));
+}
+static double wgrad_bytes(const WgradArgs& a) {
+    const double es = (double)dt_size(a.dt);
+    return es * ((double)a.K * a.Cs + 4.0 * a.K * a.Cl) + 4.0 * 16.0 * a.Cs * a.Cl;
+}
+
 template <int BM, int BN, int WM, int WN, int BKT = 32>
 static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
     const int ncls = a.form == 0 ? 1 : 4;
     dim3 grid(tiles, nsplit, ncls);
     // algorithmic FLOPs = 2 * M * Co * (taps * Ci) per class (== 2 * conv MACs, padding taps included)
-    if (g_prof) g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, st);
+    if (g_prof) g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, gconv_bytes(a), st);
     hipEvent_t e0 = g_prof ? g_prof->recs.back().e0 : nullptr, e1 = g_prof ? g_prof->recs.back().e1 : nullptr;
     if (a.dt != DT_F32) {
         launch_gconv16(id, a, grid, st, e0, e1);
@@ -488,7 +500,7 @@ void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         ((1 << (a.lgHr + a.lgWr)) % 128) == 0 && a.lgWr >= 4 && a.lgWr <= 6) {
         // all four parity classes per workgroup, input patch resident in LDS (k_gconv_up4): the short-K Generator blocks
         dim3 grid(a.M / 128);
-        if (g_prof) g_prof->begin(5, 2.0 * a.M * a.Co * (double)(4 * a.Ci) * 4, st);
+        if (g_prof) g_prof->begin(5, 2.0 * a.M * a.Co * (double)(4 * a.Ci) * 4, gconv_bytes(a), st);
         hipEvent_t e0 = g_prof ? g_prof->recs.back().e0 : nullptr, e1 = g_prof ? g_prof->recs.back().e1 : nullptr;
         if (a.Ci == 32) hipExtLaunchKernelGGL(k_gconv_up4<32>, grid, dim3(256), 0, st, e0, e1, 0, a);
         else hipExtLaunchKernelGGL(k_gconv_up4<64>, grid, dim3(256), 0, st, e0, e1, 0, a);
@@ -669,10 +681,10 @@ int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
     nsplit = (ktiles + per - 1) / per;
     dim3 grid(tiles, 1, nsplit);
     if (a.dt != DT_F32) {
-        if (g_prof) g_prof->begin(small ? 6 : 4, 2.0 * a.Cs * (double)N * a.K, st);
+        if (g_prof) g_prof->begin(small ? 6 : 4, 2.0 * a.Cs * (double)N * a.K, wgrad_bytes(a), st);
         launch_wgrad16(small, a, grid, st, g_prof ? g_prof->recs.back().e0 : nullptr, g_prof ? g_prof->recs.back().e1 : nullptr);
     } else if (g_prof) {
-        g_prof->begin(small ? 6 : 4, 2.0 * a.Cs * (double)N * a.K, st);
+        g_prof->begin(small ? 6 : 4, 2.0 * a.Cs * (double)N * a.K, wgrad_bytes(a), st);
         hipEvent_t e0 = g_prof->recs.back().e0, e1 = g_prof->recs.back().e1;
         if (small) hipExtLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, e0, e1, 0, a);
         else hipExtLaunchKernelGGL((k_wgrad<64, 64, 2, 2>), grid, dim3(256), 0, st, e0, e1, 0, a);

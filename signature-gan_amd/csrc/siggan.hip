@@ -5,6 +5,7 @@
 // parameters() order; the library owns only the workspace allocated here (NHWC activations,
 // packed weight copies, split-K slabs, reduction partials, device-side step state).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -57,6 +58,48 @@ static const int MAXL = 6;
     HIPCHK(dg_.err)
 
 static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// ------------------------------------------------------------------------------------------
+// RCCL (the collective of the data-parallel step).  The library does not link librccl: the
+// process that loads it normally holds one already (torch bundles its own copy), and a second HIP/RCCL runtime in one
+// process is what SURVEY 7 warns about.  The five entry points used are resolved with dlsym from the copy that is
+// loaded (RTLD_NOLOAD), else from the first librccl the loader finds.  Declarations follow the stable NCCL C API.
+// ------------------------------------------------------------------------------------------
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId_t;
+enum { NCCL_SUCCESS = 0, NCCL_CHAR = 0, NCCL_FLOAT32 = 7, NCCL_SUM = 0 };
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(ncclUniqueId_t*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId_t, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    const char* err = nullptr;
+};
+static Rccl* rccl() {
+    static Rccl r;
+    if (r.h || r.err) return &r;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy torch loaded
+    for (const char* n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.h) { r.err = "librccl.so was not found (load it, or import torch, before siggan_comm_*)"; return &r; }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+    r.Broadcast = (decltype(r.Broadcast))dlsym(r.h, "ncclBroadcast");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GetErrorString)
+        r.err = "librccl.so lacks one of ncclGetUniqueId / CommInitRank / CommDestroy / AllReduce / Broadcast / GetErrorString";
+    return &r;
+}
+#define NCCLCHK(x)                                                                                  \
+    do {                                                                                            \
+        int e_ = (x);                                                                               \
+        if (e_ != NCCL_SUCCESS) return fail(SIGGAN_E_HIP, "%s -> %s (%s:%d)", #x, rccl()->GetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
 
 struct PhaseKey {
     int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg, pre_real;
@@ -111,6 +154,8 @@ struct siggan_ctx {
     hipEvent_t ev_gfwd, ev_dreal;
     bool dreal_orphan;   // a D(real) forward enqueued on lane c was abandoned: the next enqueue waits for ev_dreal first
     hipError_t lane_err; // first failed event record / wait of a fork or join (checked after every phase)
+    // data-parallel communicator (siggan_comm_init): world 1 = none
+    ncclComm_t comm; int comm_rank, comm_world; int comm_err;
     int staged_B;        // batch of a real batch staged for the NEXT D step by siggan_stage_real (0: none)
     int dreal_B;         // batch whose D(real) forward siggan_g_grads already enqueued on lane c (0: none)
     int zg_stash;        // batch of an explicit G-step z handed to siggan_step_begin when the forward was not pipelined
@@ -284,6 +329,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_dreal, hipEventDisableTiming));
     c->staged_B = c->dreal_B = 0;
     c->dreal_orphan = false; c->lane_err = hipSuccess;
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1; c->comm_err = 0;
     c->g_fwd_pending = 0;
     c->zg_stash = 0;
     for (int i = 0; i < siggan_ctx::NEV; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
@@ -296,6 +342,7 @@ extern "C" int siggan_destroy(siggan_ctx* c) {
     if (!c) return SIGGAN_OK;
     DevGuard dg(c->cfg.device);
     (void)hipDeviceSynchronize();
+    if (c->comm) { (void)rccl()->CommDestroy(c->comm); c->comm = nullptr; }
     for (auto& e : c->graphs) (void)hipGraphExecDestroy(e.second);
     for (int i = 0; i < siggan_ctx::NEV; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 2; ++i) if (c->ev_bridge[i]) (void)hipEventDestroy(c->ev_bridge[i]);
@@ -443,6 +490,10 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
 // event record / wait pairs, so the same code runs eagerly and under stream capture (hipGraph).
 // ------------------------------------------------------------------------------------------
 static int lane_check(siggan_ctx* c) {
+    if (c->comm_err) {
+        const int e = c->comm_err; c->comm_err = 0;
+        return fail(SIGGAN_E_HIP, "ncclAllReduce of the gradient bucket failed: %s", rccl()->GetErrorString(e));
+    }
     if (c->lane_err == hipSuccess) return SIGGAN_OK;
     const hipError_t e = c->lane_err; c->lane_err = hipSuccess;
     return fail(SIGGAN_E_HIP, "an event record / stream wait / prepare table of the step failed: %s", hipGetErrorString(e));
@@ -720,7 +771,15 @@ static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const bool clip = k.clip > 0.f;
     // the arena holds gscale x the gradient (fp16 chains; 1 otherwise): the optimiser's multiplier takes it out again, and
     // the gradient is written back unscaled (as torch leaves a clipped .grad)
-    const float gs = k.gs / c->gscale;
+    float gs = k.gs / c->gscale;
+    if (c->comm) {
+        // the data-parallel exchange: ONE sum all-reduce of the network's flat gradient bucket over RCCL, in place, on the
+        // step's own stream (whatever runs on the side lanes -- the pipelined Generator forward behind the D bucket, the
+        // staged D(real) forward behind the G bucket -- overlaps it); the mean is taken by the optimiser's multiplier
+        const int e = rccl()->AllReduce(g, g, (size_t)n, NCCL_FLOAT32, NCCL_SUM, c->comm, L.m);
+        if (e != NCCL_SUCCESS && !c->comm_err) c->comm_err = e;
+        gs *= 1.0f / (float)c->comm_world;
+    }
     if (clip) launch_grad_sumsq(g, n, c->dev, c->partial, L.m);
     launch_adam_prepare(c->dev, steps, nt, k.lr, k.beta1, k.beta2, gs, k.clip,
                         k.mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), L.m);
@@ -739,6 +798,7 @@ static void run_phase_body(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
 static int run_phase(siggan_ctx* c, const PhaseKey& k, hipStream_t u) {
     const bool overlap = (c->mode & SIGGAN_MODE_OVERLAP) != 0;
     const bool graph = (c->mode & SIGGAN_MODE_GRAPH) != 0 && g_prof == nullptr;
+    if (graph && c->comm && k.phase >= 2) return fail(SIGGAN_E_STATE, "SIGGAN_MODE_GRAPH is not available with a communicator");
     if (!graph) {
         Lanes L{c, u, overlap ? c->s_a : u, overlap ? c->s_b : u};
         run_phase_body(c, L, k);
@@ -1050,6 +1110,55 @@ extern "C" int siggan_op_adam(siggan_ctx* c, float* p, float* g, float* m, float
     return SIGGAN_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// data-parallel communicator
+// ------------------------------------------------------------------------------------------
+extern "C" int siggan_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(SIGGAN_E_INVALID, "null argument");
+    Rccl* r = rccl();
+    if (r->err) return fail(SIGGAN_E_STATE, "%s", r->err);
+    ncclUniqueId_t id;
+    NCCLCHK(r->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return SIGGAN_OK;
+}
+extern "C" int siggan_comm_init(siggan_ctx* c, int32_t rank, int32_t world, const void* id) {
+    ENTER(c);
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(SIGGAN_E_INVALID, "bad rank / world / id");
+    if (c->comm) return fail(SIGGAN_E_STATE, "a communicator is already initialised");
+    Rccl* r = rccl();
+    if (r->err) return fail(SIGGAN_E_STATE, "%s", r->err);
+    ncclUniqueId_t uid;
+    memcpy(&uid, id, sizeof uid);
+    NCCLCHK(r->CommInitRank(&c->comm, world, uid, rank));
+    c->comm_rank = rank; c->comm_world = world;
+    return SIGGAN_OK;
+}
+extern "C" int siggan_comm_destroy(siggan_ctx* c) {
+    ENTER(c);
+    if (!c->comm) return SIGGAN_OK;
+    HIPCHK(hipDeviceSynchronize());
+    NCCLCHK(rccl()->CommDestroy(c->comm));
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    return SIGGAN_OK;
+}
+extern "C" int32_t siggan_comm_world(const siggan_ctx* c) { return c ? c->comm_world : -1; }
+extern "C" int siggan_comm_broadcast(siggan_ctx* c, void* buf_dev, int64_t bytes, int32_t root, void* stream) {
+    ENTER(c);
+    if (!buf_dev || bytes < 1 || root < 0 || root >= c->comm_world) return fail(SIGGAN_E_INVALID, "bad argument");
+    if (!c->comm) return SIGGAN_OK;                      // a single replica already holds the root's bytes
+    NCCLCHK(rccl()->Broadcast(buf_dev, buf_dev, (size_t)bytes, NCCL_CHAR, root, c->comm, (hipStream_t)stream));
+    return SIGGAN_OK;
+}
+
+extern "C" int siggan_device_info(int32_t device, int32_t* compute_units, int32_t* clock_khz, int64_t* hbm_bytes) {
+    if (!compute_units || !clock_khz || !hbm_bytes) return fail(SIGGAN_E_INVALID, "null argument");
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    *compute_units = p.multiProcessorCount; *clock_khz = p.clockRate; *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return SIGGAN_OK;
+}
+
 static Prof g_prof_store;
 extern "C" int siggan_prof_enable(siggan_ctx* c, int32_t on) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
@@ -1061,17 +1170,17 @@ extern "C" int siggan_prof_enable(siggan_ctx* c, int32_t on) {
 }
 extern "C" int32_t siggan_prof_slots(void) { return Prof::NID - 1; }
 extern "C" int siggan_prof_read(siggan_ctx* c, int32_t idx, char* name, int32_t name_cap, int64_t* launches, double* ms,
-                                double* flops) {
-    if (!c || !name || !launches || !ms || !flops || idx < 0 || idx >= Prof::NID - 1) return fail(SIGGAN_E_INVALID, "bad argument");
+                                double* flops, double* bytes) {
+    if (!c || !name || !launches || !ms || !flops || !bytes || idx < 0 || idx >= Prof::NID - 1) return fail(SIGGAN_E_INVALID, "bad argument");
     DevGuard dg_(c->cfg.device); HIPCHK(dg_.err);
     HIPCHK(hipDeviceSynchronize());
     snprintf(name, name_cap, "%s", Prof::name(idx));
-    *launches = 0; *ms = 0.0; *flops = 0.0;
+    *launches = 0; *ms = 0.0; *flops = 0.0; *bytes = 0.0;
     for (auto& r : g_prof_store.recs) {
         if (r.id != idx) continue;
         float t = 0.f;
         HIPCHK(hipEventElapsedTime(&t, r.e0, r.e1));
-        *launches += 1; *ms += t; *flops += r.flops;
+        *launches += 1; *ms += t; *flops += r.flops; *bytes += r.bytes;
     }
     return SIGGAN_OK;
 }

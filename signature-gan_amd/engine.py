@@ -51,6 +51,7 @@ class Engine:
         self.f16_grad_scale = float(f16_grad_scale)
         self._h = None
         self._staged = None
+        self._comm = None
         self._create_context()
         h = self._h
         self.g_entries = layout.generator_entries(latent_dim, image_size)
@@ -97,6 +98,9 @@ class Engine:
         than ``max_batch`` arrives; parameters, moments and buffers are untouched."""
         if batch <= self.max_batch:
             return
+        if self._comm is not None:
+            raise RuntimeError(f"batch {batch} exceeds max_batch {self.max_batch}: a context that holds a communicator "
+                               "cannot be re-created on one rank alone; size max_batch for the largest batch up front")
         torch.cuda.synchronize(self.device)
         seed, offset = self.rng_state()          # the z / dropout stream continues where the old context stood
         self.lib.siggan_destroy(self._h)
@@ -160,6 +164,39 @@ class Engine:
         s, o = C.c_uint64(), C.c_uint64()
         _lib.check(self.lib.siggan_rng_state(self._h, C.byref(s), C.byref(o)))
         return int(s.value), int(o.value)
+
+    # ---- data parallelism: the library's own RCCL communicator ----------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id (rank 0 draws it, every rank passes the same bytes to comm_init)."""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().siggan_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        """From here on d_apply / g_apply (hence d_step / g_step / train_step) sum-all-reduce the gradient bucket over
+        RCCL inside the library and average it; world == 1 is allowed (the collective runs and changes nothing)."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of Engine.comm_unique_id()")
+        self._comm_id = C.create_string_buffer(bytes(unique_id), 128)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.siggan_comm_init(self._h, int(rank), int(world), self._comm_id))
+        self._comm = (int(rank), int(world), bytes(unique_id))
+
+    def comm_destroy(self):
+        _lib.check(self.lib.siggan_comm_destroy(self._h))
+        self._comm = None
+
+    @property
+    def comm_world(self):
+        return int(self.lib.siggan_comm_world(self._h))
+
+    def comm_broadcast(self, tensor, root=0):
+        """In-place broadcast of a device tensor from ``root`` over the library communicator (no-op without one)."""
+        if tensor.device != self.device or not tensor.is_contiguous():
+            raise ValueError("comm_broadcast needs a contiguous tensor on the engine's device")
+        _lib.check(self.lib.siggan_comm_broadcast(self._h, _ptr(tensor), tensor.numel() * tensor.element_size(), int(root),
+                                                  self._stream()))
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -344,6 +381,13 @@ class Engine:
         _lib.check(self.lib.siggan_op_randn(self._h, _ptr(out), n, self._stream()))
         return out
 
+    @staticmethod
+    def device_info(index=0):
+        """(compute units, shader clock in kHz, HBM bytes) of a device: what the roofline peaks are derived from."""
+        cu, khz, mem = C.c_int32(), C.c_int32(), C.c_int64()
+        _lib.check(_lib.load().siggan_device_info(int(index), C.byref(cu), C.byref(khz), C.byref(mem)))
+        return cu.value, khz.value, mem.value
+
     def prof_enable(self, on=True):
         _lib.check(self.lib.siggan_prof_enable(self._h, int(on)))
 
@@ -352,10 +396,11 @@ class Engine:
         out = []
         for i in range(self.lib.siggan_prof_slots()):
             name = C.create_string_buffer(64)
-            n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
-            _lib.check(self.lib.siggan_prof_read(self._h, i, name, 64, C.byref(n), C.byref(ms), C.byref(fl)))
+            n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            _lib.check(self.lib.siggan_prof_read(self._h, i, name, 64, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
             if n.value:
-                out.append({"name": name.value.decode(), "launches": n.value, "ms": ms.value, "flops": fl.value})
+                out.append({"name": name.value.decode(), "launches": n.value, "ms": ms.value, "flops": fl.value,
+                            "bytes": by.value})
         return out
 
     def debug_tensor(self, name, index, shape):

@@ -80,3 +80,32 @@ def test_two_rank_step_equals_single_process_emulation(tmp_path):
         assert torch.equal(got["state"][k], v), f"{k}: the two-rank run differs from the emulation"
     assert got["metrics"]["d_loss"] > 0 and got["metrics"]["g_loss"] > 0
     e0.close(); e1.close()
+
+
+def test_library_rccl_communicator_world_1_is_bit_identical():
+    """The collective inside the library (siggan_comm_init -> ncclCommInitRank, ncclAllReduce of the gradient bucket in
+    siggan_d_apply / siggan_g_apply, ncclBroadcast of the initial state) on ONE rank: a real RCCL communicator on cuda:0
+    whose all-reduce must leave every result bit-identical to the run without a communicator."""
+    from hipcommon import cuda, make_engine
+    from signature_gan_amd.dp import DataParallelStep
+    real, z_d, z_g, masks = _inputs()
+
+    def run(comm):
+        eng = make_engine(SIZE, LATENT, GB, warm=True)
+        if comm:
+            eng.comm_init(0, 1, eng.comm_unique_id())
+            assert eng.comm_world == 1
+        dp = DataParallelStep(eng, clip=0.5, transport="lib" if comm else "host")
+        dp.sync_initial_state()
+        mets = [dp.step(cuda(real), cuda(z_d), cuda(z_g), masks, sync=True) for _ in range(3)]
+        st = _state(eng)
+        if comm:
+            eng.comm_destroy()
+        eng.close()
+        return mets, st
+
+    m0, s0 = run(False)
+    m1, s1 = run(True)
+    assert m0 == m1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
