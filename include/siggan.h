@@ -141,6 +141,18 @@ int siggan_rng_state(siggan_ctx *ctx, uint64_t *seed, uint64_t *offset);
 #define SIGGAN_MODE_OVERLAP 2
 int siggan_set_mode(siggan_ctx *ctx, int32_t mode);
 
+/* Which of the reference's two G+D iterations the step calls implement (default SIGGAN_STEP_TRAINER):
+ *   TRAINER   GANTrainer._train_discriminator / _train_generator == VanillaGAN.train_*_step (train_vanilla_gan_signatures.py:
+ *             281-376): D step with G in eval mode on its own z; G step with D in eval mode (no dropout), its own z, target 1.
+ *   ABLATION  AblationGANTrainer.train_epoch (ablation_vanilla_gan_signatures.py:397-467): both nets stay in train mode; ONE
+ *             Generator forward per iteration (BatchNorm batch statistics) whose detached output feeds the D update and
+ *             through which the G update back-propagates; the G update's D pass draws fresh dropout masks and its target
+ *             is the smoothed real label (hp->label_smoothing of siggan_g_grads).  Call order per iteration:
+ *             siggan_d_grads(real, z, masks) -> siggan_d_apply -> siggan_g_grads(batch, z = NULL) -> siggan_g_apply; explicit
+ *             masks are three sets (real pass, fake pass of the D update, fake pass of the G update). */
+enum { SIGGAN_STEP_TRAINER = 0, SIGGAN_STEP_ABLATION = 1 };
+int siggan_set_step_variant(siggan_ctx *ctx, int32_t variant);
+
 /* ---- forward passes ---------------------------------------------------------------------- */
 /* z_dev (B,latent) -> images_dev (B,1,S,S) in [-1,1].  training!=0: BatchNorm batch statistics,
  * running stats and num_batches_tracked updated (nn.Module.train()); 0: running stats (eval). */

@@ -367,6 +367,40 @@ def g_step(g_sd, d_sd, g_opt: AdamState, z, size, lr=2e-4, beta1=0.5, beta2=0.99
     return metrics, grads
 
 
+def ablation_step(g_sd, d_sd, g_opt: AdamState, d_opt: AdamState, real, z, masks_real, masks_fake, masks_g, size,
+                  lr_g=2e-4, lr_d=2e-4, beta1=0.5, beta2=0.999, label_smoothing=0.9, dropout: float = 0.25, q=None):
+    """One iteration of AblationGANTrainer.train_epoch (ablation_vanilla_gan_signatures.py:397-467), for the standard
+    (ReLU) Generator: both networks in train mode for the whole iteration; ONE Generator forward (BatchNorm batch
+    statistics, running stats updated) whose detached image feeds the D update (:414-430) and through which the G update
+    back-propagates (:432-441); the G update runs the UPDATED Discriminator, still in train mode (a third set of dropout
+    masks), against the smoothed real label.  Returns (metrics, d_grads, g_grads)."""
+    g_names = param_names(g_state_specs(z.shape[1], size))
+    d_names = param_names(d_state_specs(size, real.shape[1]))
+    g_leaf = dict(g_sd)
+    g_leaf.update(_leafs(g_sd, g_names))
+    fake = g_forward(g_leaf, z, training=True, size=size, q=q)
+    for k in g_sd:
+        if k not in g_names:
+            g_sd[k] = g_leaf[k]
+    d_leaf = _leafs(d_sd, d_names)
+    real_preds = d_forward(d_leaf, real, size, masks_real, dropout, q=q)
+    fake_preds = d_forward(d_leaf, fake.detach(), size, masks_fake, dropout, q=q)
+    loss_real, loss_fake = bce(real_preds, label_smoothing), bce(fake_preds, 0.0)
+    d_loss = loss_real + loss_fake
+    gl = torch.autograd.grad(d_loss, [d_leaf[k] for k in d_names])
+    d_grads = {k: g.detach() for k, g in zip(d_names, gl)}
+    d_opt.apply(d_sd, d_grads, lr_d, beta1, beta2)
+    preds_g = d_forward(d_sd, fake, size, masks_g, dropout, q=q)            # the updated D, dropout still active
+    g_loss = bce(preds_g, label_smoothing)
+    gl = torch.autograd.grad(g_loss, [g_leaf[k] for k in g_names])
+    g_grads = {k: g.detach() for k, g in zip(g_names, gl)}
+    g_opt.apply(g_sd, g_grads, lr_g, beta1, beta2)
+    metrics = {"d_loss": float(d_loss.detach()), "d_loss_real": float(loss_real.detach()), "d_loss_fake": float(loss_fake.detach()),
+               "d_real_mean": float(real_preds.detach().mean()), "d_fake_mean": float(fake_preds.detach().mean()),
+               "g_loss": float(g_loss.detach()), "g_fake_mean": float(preds_g.detach().mean())}
+    return metrics, d_grads, g_grads
+
+
 def average_grads(per_rank: Sequence[Dict[str, Tensor]]) -> Dict[str, Tensor]:
     """Data-parallel emulation: mean of the replicas' gradients."""
     out = {}

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "siggan_seed": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
     "siggan_rng_state": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "siggan_set_mode": (C.c_int, [_P, _I32]),
+    "siggan_set_step_variant": (C.c_int, [_P, _I32]),
     "siggan_g_forward": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
     "siggan_d_forward": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P]),
     "siggan_d_step": (C.c_int, [_P, _P, _I32, _P, _P, C.POINTER(Hyper), _P, _P, _P]),

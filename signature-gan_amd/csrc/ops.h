@@ -60,6 +60,17 @@ bool launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s);   // false
 void launch_fc_fwd(int dt, const float* z, const float* Wt, const float* b, void* y, int B, int K, int C0, hipStream_t s,
                    const float* bn_affine_relu = nullptr, const DevState* st = nullptr, uint32_t stream_id = 0,
                    float* z_out = nullptr);
+// fc.hip: Linear + BatchNorm1d + ReLU in ONE launch on the fp32 matrix cores.  bne != nullptr: eval mode (folded [scale | shift]
+// table, only `a` is written); else training: y (pre-BN), a, the bn table [scale | shift | mean | rstd | . | .] the backward
+// reuses, and the running statistics / batch counter are written.  W is the torch-layout weight (no transposed copy).
+// Returns false (nothing launched) when the shape is outside what the kernel covers (B > 256, or RNG draw with K % 4 != 0).
+bool launch_fc_fwd_fused(int dt, const float* z, const float* W, const float* bias, void* y, void* a, const float* gamma,
+                         const float* beta, float* rmean, float* rvar, int64_t* batches, float* bn, const float* bne,
+                         float* z_out, const DevState* st, uint32_t sid, int B, int K, int C0, float momentum, float eps,
+                         hipStream_t s);
+// ReLU mask + BatchNorm1d backward + dW / db of the Linear in ONE launch: da, y element type dt; dW, db, dgamma, dbeta fp32 (torch order)
+bool launch_fc_bwd_fused(int dt, const void* da, const void* y, const float* z, float* bn, float* dW, float* db, float* dgamma,
+                         float* dbeta, int B, int K, int C0, hipStream_t s);
 // dW[f][k] = sum_n dy[n][f'] z[n][k];  db[f] = sum_n dy[n][f']
 void launch_fc_wgrad(int dt, const void* dy, const float* z, float* dW, float* db, int B, int K, int C0, hipStream_t s);
 

@@ -4,40 +4,23 @@
 // segments) and per-channel reductions are two-stage (per-chunk partials, then a finalize
 // kernel that adds the partials in chunk order), so results are bitwise reproducible.
 #include "ops.h"
+#include "rng.h"
 
 namespace siggan {
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // =========================================================================================
-// RNG: Philox4x32-10
+// RNG (rng.h): Philox4x32-10
 // =========================================================================================
-__device__ __forceinline__ uint4 philox(uint4 c, uint2 k) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += W0; k.y += W1;
-    }
-    return c;
-}
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-
 __device__ __forceinline__ uint4 draw(const DevState* st, uint64_t idx, uint32_t stream_id, uint32_t ctr_add = 0) {
-    const unsigned long long ctr = st->rng_ctr + ctr_add, seed = st->seed;
-    return philox(make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), stream_id, (uint32_t)ctr),
-                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(ctr >> 32)));
+    return draw_raw(st->seed, st->rng_ctr + ctr_add, idx, stream_id);
 }
 
 __global__ void k_randn(float* __restrict__ out, int64_t n, const DevState* __restrict__ st, uint32_t sid) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t * 4 >= n) return;
-    const uint4 r = draw(st, (uint64_t)t, sid);
-    const float r0 = sqrtf(-2.0f * logf(u01(r.x))), r1 = sqrtf(-2.0f * logf(u01(r.z)));
-    const float a0 = 6.283185307179586f * u01(r.y), a1 = 6.283185307179586f * u01(r.w);
-    const float v[4] = {r0 * cosf(a0), r0 * sinf(a0), r1 * cosf(a1), r1 * sinf(a1)};
+    const f32x4 v = normal4(draw(st, (uint64_t)t, sid));
     for (int j = 0; j < 4 && t * 4 + j < n; ++j) out[t * 4 + j] = v[j];
 }
 __global__ void k_mask_to_noise(const float* __restrict__ m, float* __restrict__ out, int64_t n, float inv) {
@@ -385,10 +368,8 @@ __global__ __launch_bounds__(256) void k_fc_fwd(const float* __restrict__ z, con
             const int q = i * 4;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (q < cnt) {
-                const uint4 r = draw(st, (uint64_t)(e0 / 4 + i), sid);
-                const float r0 = sqrtf(-2.0f * logf(u01(r.x))), r1 = sqrtf(-2.0f * logf(u01(r.z)));
-                const float a0 = 6.283185307179586f * u01(r.y), a1 = 6.283185307179586f * u01(r.w);
-                v[0] = r0 * cosf(a0); v[1] = r0 * sinf(a0); v[2] = r1 * cosf(a1); v[3] = r1 * sinf(a1);
+                const f32x4 nv = normal4(draw(st, (uint64_t)(e0 / 4 + i), sid));
+                v[0] = nv[0]; v[1] = nv[1]; v[2] = nv[2]; v[3] = nv[3];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

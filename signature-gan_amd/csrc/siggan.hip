@@ -102,13 +102,13 @@ static Rccl* rccl() {
     } while (0)
 
 struct PhaseKey {
-    int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg, pre_real;
+    int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg, pre_real, variant;
     float* mt;   // where the phase writes its metrics (caller's buffer, or the workspace one)
     double lr, beta1, beta2, eps;
     float ls, clip, gs;
     bool operator==(const PhaseKey& o) const {
         return phase == o.phase && B == o.B && has_z == o.has_z && has_masks == o.has_masks && g_dirty == o.g_dirty &&
-               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && pre_real == o.pre_real && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
+               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && pre_real == o.pre_real && variant == o.variant && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
                clip == o.clip && gs == o.gs;
     }
 };
@@ -118,6 +118,9 @@ struct siggan_ctx {
     int S, latent, Lg, Ld, Bm;
     int dt;             // element type of the activation / gradient tensors and of the MFMA weight packs (act.h)
     size_t es;          // its size in bytes
+    int variant;        // SIGGAN_STEP_TRAINER / SIGGAN_STEP_ABLATION (siggan_set_step_variant)
+    bool abl_masks;     // ablation step: the D half was given explicit masks, the third set waits in mask_stage for the G half
+    bool fc_fused;      // Generator.fc runs as the one-launch MFMA kernels of fc.hip (max_batch <= 256, latent % 4 == 0)
     float gscale;       // gradient scale of the backward chains (fp16: keeps small gradients out of the subnormals; else 1)
     int gC[MAXL + 1];   // generator channel chain gC[0..Lg]  (generator_vanilla_gan.py:131-149)
     int dC[MAXL + 1];   // discriminator chain dC[0]=1, dC[1..Ld] (discriminator_vanilla_gan.py:131-194)
@@ -239,6 +242,8 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     if (!c) return fail(SIGGAN_E_NOMEM, "out of host memory");
     c->cfg = *cfg; c->S = cfg->image_size; c->latent = cfg->latent_dim; c->Bm = cfg->max_batch;
     c->dt = cfg->dtype; c->es = dt_size(c->dt);
+    c->fc_fused = cfg->max_batch <= 256 && (cfg->latent_dim & 3) == 0;
+    c->variant = SIGGAN_STEP_TRAINER; c->abl_masks = false;
     // fp16 stores activation gradients of order 1e-7..1e-3: a power-of-two scale (exact to apply and to remove) lifts
     // them clear of the fp16 subnormals; bf16 has fp32's exponent range and needs none
     c->gscale = c->dt == DT_F16 ? (cfg->f16_grad_scale > 0.f ? cfg->f16_grad_scale : 1024.f) : 1.0f;
@@ -300,7 +305,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->img_g, Bm * c->S * c->S);
         carve(&c->real_stage, Bm * c->S * c->S);
         carve(&c->real_next, Bm * c->S * c->S);
-        { int64_t sumC = 0; for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l]; carve(&c->mask_stage, 2 * Bm * sumC); }
+        { int64_t sumC = 0; for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l]; carve(&c->mask_stage, 3 * Bm * sumC); }
         carve(&c->metrics, SIGGAN_M_COUNT);
         carve_t(&c->op_pack, (int64_t)512 * 512 * 16);
         carve(&c->zeros, 64);
@@ -442,8 +447,10 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
     if (do_g) {
         PrepTable t; t.njobs = 0; t.overflow = 0;
         PrepJob j; memset(&j, 0, sizeof j);
-        j.type = PREP_FC_T; j.O = c->latent; j.I = c->gC[0]; j.src = GP(c, gi_fc_w()); j.dst = c->wfc_t;
-        prep_add(t, j, (long long)c->latent * c->F);
+        if (!c->fc_fused) {                                            // the generic fc kernel reads a k-major copy
+            j.type = PREP_FC_T; j.O = c->latent; j.I = c->gC[0]; j.src = GP(c, gi_fc_w()); j.dst = c->wfc_t;
+            prep_add(t, j, (long long)c->latent * c->F);
+        }
         for (int l = 1; l <= c->Lg; ++l) {
             const long long n = (long long)c->gC[l - 1] * c->gC[l] * 16;
             memset(&j, 0, sizeof j);
@@ -531,7 +538,12 @@ static GConvArgs gconv_args(siggan_ctx* c) {
 static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s,
                            float* partial = nullptr, float* slab_k = nullptr, uint32_t rng_sid = 0, float* z_out = nullptr) {
     if (!partial) partial = c->partial;
-    if (!training) {     // eval: BatchNorm1d + ReLU folded into the fc epilogue
+    // fc + BatchNorm1d + ReLU: one MFMA launch (fc.hip) whenever the shape allows, else the generic kernels
+    if (c->fc_fused && launch_fc_fwd_fused(c->dt, z, GP(c, gi_fc_w()), GP(c, gi_fc_b()), c->fc_y, c->g_a[0], GP(c, gi_bn0_w()),
+                                          GP(c, gi_bn0_b()), c->st.g_bn_running_mean, c->st.g_bn_running_var, c->st.g_bn_batches,
+                                          c->g_bn[0], training ? nullptr : c->g_bne[0], z_out, c->dev, rng_sid, B, c->latent,
+                                          c->gC[0], BN_MOMENTUM, BN_EPS, s)) {
+    } else if (!training) {     // eval: BatchNorm1d + ReLU folded into the fc epilogue
         launch_fc_fwd(c->dt, z, c->wfc_t, GP(c, gi_fc_b()), c->g_a[0], B, c->latent, c->gC[0], s, c->g_bne[0], c->dev, rng_sid, z_out);
     } else {
         launch_fc_fwd(c->dt, z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s, nullptr, c->dev, rng_sid, z_out);
@@ -660,9 +672,12 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
         launch_gconv(a, L.m);
     }
-    launch_bn_bwd(c->dt, c->g_da[0], c->fc_y, B, c->F, c->g_bn[0], c->partial, GG(c, gi_bn0_w()), GG(c, gi_bn0_b()),
-                  c->gC[0], L.m);
-    launch_fc_wgrad(c->dt, c->g_da[0], z, GG(c, gi_fc_w()), GG(c, gi_fc_b()), B, c->latent, c->gC[0], L.m);
+    if (!(c->fc_fused && launch_fc_bwd_fused(c->dt, c->g_da[0], c->fc_y, z, c->g_bn[0], GG(c, gi_fc_w()), GG(c, gi_fc_b()),
+                                             GG(c, gi_bn0_w()), GG(c, gi_bn0_b()), B, c->latent, c->gC[0], L.m))) {
+        launch_bn_bwd(c->dt, c->g_da[0], c->fc_y, B, c->F, c->g_bn[0], c->partial, GG(c, gi_bn0_w()), GG(c, gi_bn0_b()),
+                      c->gC[0], L.m);
+        launch_fc_wgrad(c->dt, c->g_da[0], z, GG(c, gi_fc_w()), GG(c, gi_fc_b()), B, c->latent, c->gC[0], L.m);
+    }
     L.join(L.a); L.join(L.b);
 }
 
@@ -711,22 +726,33 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // D(real) beside the Generator (train...py:309) -- unless the previous siggan_g_grads already ran it
     // (siggan_stage_real) beside its Generator backward; then bce only has to wait for that lane
     if (k.pre_real != 2) d_forward_rows(c, c->real_stage, 0, B, drop, L.a, c->slab_k2);
-    g_forward_pass(c, k.has_z ? c->z : nullptr, B, false, c->img, L.m, nullptr, nullptr, 1, c->z);   // G.eval(), no grad (train...py:314-315)
+    const float* fake = c->img;
+    if (k.variant == SIGGAN_STEP_ABLATION) {
+        // ablation_vanilla_gan_signatures.py:397-448: both nets in train mode and ONE Generator forward per iteration --
+        // BatchNorm batch statistics (+ running update), activations kept: the D half sees fake.detach(), the G half
+        // back-propagates through the very same forward
+        g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, L.m, nullptr, nullptr, 2, c->z_g);
+        L.record(c->ev_gfwd, L.m);
+        fake = c->img_g;
+    } else {
+        g_forward_pass(c, k.has_z ? c->z : nullptr, B, false, c->img, L.m, nullptr, nullptr, 1, c->z);   // G.eval(), no grad (train...py:314-315)
+    }
     L.join(L.a);
     // siggan_step_begin: the G step's training forward depends on nothing the D step changes, so it
     // runs on its own lane beside D(fake) and the D step's backward (after the eval forward above: it
     // moves the BatchNorm running statistics and reuses the activation buffers; its own image / z /
     // scratch).  It forks HERE but is enqueued after D(fake), whose kernels the dispatcher should see first.
     hipEvent_t e_spec = nullptr;
-    if (k.spec_g) { e_spec = L.next(); L.record(e_spec, L.m); }
-    d_forward_rows(c, c->img, B, B, drop, L.m, c->slab_k);           // D(fake) into rows [B, 2B)
+    const bool spec_fwd = k.spec_g && k.variant != SIGGAN_STEP_ABLATION;
+    if (spec_fwd) { e_spec = L.next(); L.record(e_spec, L.m); }
+    d_forward_rows(c, fake, B, B, drop, L.m, c->slab_k);             // D(fake) into rows [B, 2B)
     if (k.pre_real == 2) L.wait(L.m, c->ev_dreal);
-    if (k.spec_g) {
+    if (spec_fwd) {
         L.wait(c->s_c, e_spec);
         g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2, 2, c->z_g);
         L.record(c->ev_gfwd, c->s_c);
     }
-    d_backward_pass(c, L, c->real_stage, B, c->img, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0});
+    d_backward_pass(c, L, c->real_stage, B, fake, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0});
 }
 
 static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
@@ -743,8 +769,18 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         L.join(L.a);
         zg = c->z; img = c->img;
     }
-    d_forward_rows(c, img, 0, B, false, L.m, c->slab_k);             // D.eval(): dropout off (train...py:350)
-    d_backward_pass(c, L, img, B, img, B, false, false, true, BceSpec{B, 1.0f, 1.0f, k.mt, 1});   // through D into the image; no D weight grads
+    // trainer step: D.eval() -- dropout off, target 1.0 (train...py:350,360).  Ablation step: D stays in train mode -- a
+    // fresh set of dropout masks -- and the target is the smoothed real label (ablation...py:441-442)
+    const bool abl = k.variant == SIGGAN_STEP_ABLATION;
+    const bool gdrop = abl && c->cfg.dropout > 0.f;
+    if (gdrop) {
+        int64_t sumC = 0;
+        for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l];
+        make_noise(c, k.has_masks ? c->mask_stage + (int64_t)2 * B * sumC : nullptr, B, 0, 1, L.m);
+    }
+    const float gy = abl ? k.ls : 1.0f;
+    d_forward_rows(c, img, 0, B, gdrop, L.m, c->slab_k);
+    d_backward_pass(c, L, img, B, img, B, gdrop, false, true, BceSpec{B, gy, gy, k.mt, 1});   // through D into the image; no D weight grads
     if (k.pre_real) {
         // siggan_stage_real: the NEXT D step's D(real) forward needs the Discriminator as it is now (its
         // update is behind us) and the activation rows this step is done with: run it on lane c beside the
@@ -856,6 +892,14 @@ static int finish_metrics(siggan_ctx* c, float* metrics_dev, float* metrics_host
 // ------------------------------------------------------------------------------------------
 // public passes
 // ------------------------------------------------------------------------------------------
+extern "C" int siggan_set_step_variant(siggan_ctx* c, int32_t variant) {
+    if (!c) return fail(SIGGAN_E_INVALID, "null context");
+    if (variant != SIGGAN_STEP_TRAINER && variant != SIGGAN_STEP_ABLATION) return fail(SIGGAN_E_INVALID, "unknown step variant %d", variant);
+    if (c->g_fwd_pending || c->pending) return fail(SIGGAN_E_STATE, "a step is in flight");
+    c->variant = variant;
+    return SIGGAN_OK;
+}
+
 extern "C" int siggan_set_mode(siggan_ctx* c, int32_t mode) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     c->mode = mode;
@@ -910,6 +954,11 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     if (c->g_fwd_pending) return fail(SIGGAN_E_STATE, "siggan_step_begin must be followed by siggan_g_grads before the next D step");
     // the speculative forward needs its own lane: without overlap (or under graph replay) it is skipped
     if (spec_g && ((c->mode & SIGGAN_MODE_OVERLAP) == 0 || (c->mode & SIGGAN_MODE_GRAPH) != 0 || g_prof != nullptr)) spec_g = false;
+    const bool abl = c->variant == SIGGAN_STEP_ABLATION;
+    if (abl) {                                 // one z per iteration: it belongs to the (single, training-mode) Generator forward
+        if (zg_dev) return fail(SIGGAN_E_INVALID, "the ablation step has one latent batch per iteration: pass it as z_dev");
+        zg_dev = z_dev; z_dev = nullptr; spec_g = true;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int B = batch;
     const size_t img_bytes = (size_t)B * c->S * c->S * sizeof(float);
@@ -924,12 +973,13 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     if (z_dev && z_dev != c->z) HIPCHK(hipMemcpyAsync(c->z, z_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     int64_t sumC = 0;
     for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l];
-    if (masks_dev) HIPCHK(hipMemcpyAsync(c->mask_stage, masks_dev, (size_t)2 * B * sumC * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (masks_dev) HIPCHK(hipMemcpyAsync(c->mask_stage, masks_dev, (size_t)(abl ? 3 : 2) * B * sumC * sizeof(float), hipMemcpyDeviceToDevice, s));
+    c->abl_masks = abl && masks_dev != nullptr;
     if (zg_dev) HIPCHK(hipMemcpyAsync(c->z_g, zg_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     c->zg_stash = (!spec_g && zg_dev) ? B : 0;
     PhaseKey k = make_key(c, 0, B, z_dev != nullptr, masks_dev != nullptr, hp, metrics_dev);
     c->metrics_last = k.mt;
-    k.spec_g = spec_g; k.has_zg = spec_g && zg_dev != nullptr; k.pre_real = pre_real;
+    k.spec_g = spec_g; k.has_zg = spec_g && zg_dev != nullptr; k.pre_real = pre_real; k.variant = c->variant;
     if ((rc = run_phase(c, k, s))) return rc;
     c->g_dirty = c->d_dirty = false;
     if (spec_g) { c->g_fwd_pending = B; c->g_dirty = true; }   // running statistics moved
@@ -1005,6 +1055,8 @@ extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, 
     if ((rc = settle(c, s))) return rc;
     const int B = batch;
     const bool spec = c->g_fwd_pending != 0;
+    if (c->variant == SIGGAN_STEP_ABLATION && !spec)
+        return fail(SIGGAN_E_STATE, "ablation step: siggan_g_grads follows the siggan_d_grads / siggan_d_apply of the same iteration");
     if (spec && (c->g_fwd_pending != B || z_dev))
         return fail(SIGGAN_E_STATE, "siggan_g_grads after siggan_step_begin must use the same batch and no explicit z (pass it to step_begin)");
     if (!spec && !z_dev && c->zg_stash == B) z_dev = c->z_g;          // z given to a step_begin that could not pipeline
@@ -1012,7 +1064,8 @@ extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, 
     if (!spec && z_dev && z_dev != c->z) HIPCHK(hipMemcpyAsync(c->z, z_dev, (size_t)B * c->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     PhaseKey k = make_key(c, 1, B, z_dev != nullptr, false, hp, metrics_dev);
     c->metrics_last = k.mt;
-    k.spec_g = spec;
+    k.spec_g = spec; k.variant = c->variant; k.has_masks = c->abl_masks;
+    c->abl_masks = false;
     // a staged next batch: start its D(real) forward beside this Generator backward (own lane: eager overlap mode only)
     k.pre_real = c->staged_B == B && c->dreal_B == 0 && (c->mode & SIGGAN_MODE_OVERLAP) != 0 && (c->mode & SIGGAN_MODE_GRAPH) == 0 &&
                  g_prof == nullptr && c->pending == 0;

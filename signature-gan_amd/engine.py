@@ -153,6 +153,28 @@ class Engine:
         """Step-phase execution mode: hipGraph replay and/or side-stream overlap (default: overlap only)."""
         _lib.check(self.lib.siggan_set_mode(self._h, (1 if graph else 0) | (2 if overlap else 0)))
 
+    def set_step_variant(self, variant="trainer"):
+        """'trainer': the reference's GANTrainer / VanillaGAN iteration (default).  'ablation': AblationGANTrainer.train_epoch's
+        (ablation_vanilla_gan_signatures.py:397-467) -- both nets in train mode, one shared Generator forward, G target =
+        smoothed label; see ablation_step."""
+        v = {"trainer": 0, "ablation": 1}[variant]
+        _lib.check(self.lib.siggan_set_step_variant(self._h, v))
+        self.step_variant = variant
+
+    def ablation_step(self, real, z=None, masks=None, lr_d=2e-4, lr_g=2e-4, beta1=0.5, beta2=0.999, eps=1e-8,
+                      label_smoothing=0.9, sync=True):
+        """One iteration of the ablation harness' loop (needs set_step_variant('ablation')): masks, if given, are the three
+        Dropout2d mask sets (real pass, fake pass of the D update, fake pass of the G update), each one (B, C_l) per block."""
+        if getattr(self, "step_variant", "trainer") != "ablation":
+            raise RuntimeError("call set_step_variant('ablation') first")
+        self.d_compute_grads(real, z, masks, label_smoothing, mask_passes=3)
+        dm = self.d_apply(lr_d, beta1, beta2, eps, None, 1.0, sync)
+        self.g_compute_grads(real.shape[0], label_smoothing=label_smoothing)
+        gm = self.g_apply(lr_g, beta1, beta2, eps, None, 1.0, sync)
+        if sync:
+            dm.update(gm)
+        return dm
+
     def seed(self, seed, offset=0):
         """(Re)position the library RNG (z, dropout tables): Philox key ``seed``, call counter ``offset`` (the counter
         ticks once per optimiser update, i.e. twice per G+D step)."""
@@ -256,7 +278,7 @@ class Engine:
     D_KEYS = ("d_loss", "d_loss_real", "d_loss_fake", "d_real_mean", "d_fake_mean", "d_real_acc", "d_fake_acc")
     G_KEYS = ("g_loss", "g_fake_mean")
 
-    def d_compute_grads(self, real, z=None, masks=None, label_smoothing=0.9):
+    def d_compute_grads(self, real, z=None, masks=None, label_smoothing=0.9, mask_passes=2):
         real = _f32(real, self.device, "real_images")
         s = self.image_size
         if real.dim() != 4 or tuple(real.shape[1:]) != (1, s, s):
@@ -266,7 +288,7 @@ class Engine:
         z = _f32(z, self.device, "noise")
         if z is not None and tuple(z.shape) != (b, self.latent_dim):
             raise ValueError(f"noise must be ({b}, {self.latent_dim})")
-        masks = self._masks(masks, b, 2)
+        masks = self._masks(masks, b, mask_passes)
         hp = self._hyper(0.0, 0.5, 0.999, label_smoothing=label_smoothing)
         self._staged = None
         _lib.check(self.lib.siggan_d_grads(self._h, _ptr(real), b, _ptr(z), _ptr(masks), C.byref(hp), _ptr(self.metrics),
@@ -330,12 +352,12 @@ class Engine:
         self.d_compute_grads(real, z, masks, label_smoothing)
         return self.d_apply(lr, beta1, beta2, eps, clip, 1.0, sync)
 
-    def g_compute_grads(self, batch, z=None):
+    def g_compute_grads(self, batch, z=None, label_smoothing=0.9):
         self._check_batch(batch)
         z = _f32(z, self.device, "noise")
         if z is not None and tuple(z.shape) != (batch, self.latent_dim):
             raise ValueError(f"noise must be ({batch}, {self.latent_dim})")
-        hp = self._hyper(0.0, 0.5, 0.999)
+        hp = self._hyper(0.0, 0.5, 0.999, label_smoothing=label_smoothing)
         _lib.check(self.lib.siggan_g_grads(self._h, batch, _ptr(z), C.byref(hp), _ptr(self.metrics), self._stream()))
 
     def g_apply(self, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8, clip=None, grad_scale=1.0, sync=True):

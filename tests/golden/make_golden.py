@@ -280,6 +280,53 @@ def make_spectral_norm():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_ablation_step():
+    """(xi) one iteration of AblationGANTrainer.train_epoch (ablation_vanilla_gan_signatures.py:397-467) replayed statement by
+    statement on the reference's own Generator / Discriminator / BCELoss / Adam objects (that file itself cannot be
+    imported here: torchvision absent; its ConfigurableGenerator with activation='relu' is layer for layer the standard
+    Generator, ablation...py:216-328 vs generator_vanilla_gan.py:124-163)."""
+    out = {}
+    for size, latent, B in ((64, 100, 8), (128, 128, 4)):
+        m = fresh_model(size, latent, warm=True)
+        G, D, crit = m.generator, m.discriminator, m.criterion
+        real = torch.from_numpy(I.gen_real(B, size, SEED_REAL))
+        z = torch.from_numpy(I.gen_z(B, latent, SEED_Z))
+        ls = 0.9
+        G.train(); D.train()                                               # :403-404
+        tap = MaskTap(D)
+        torch.manual_seed(SEED_TORCH + 5)
+        real_labels, fake_labels = torch.full((B, 1), ls), torch.zeros(B, 1)   # :419-420
+        m.d_optimizer.zero_grad()                                           # :423
+        d_real_output = D(real)                                             # :426
+        d_real_loss = crit(d_real_output, real_labels)
+        fake_images = G(z)                                                  # :431
+        d_fake_output = D(fake_images.detach())                             # :432
+        d_fake_loss = crit(d_fake_output, fake_labels)
+        d_loss = d_real_loss + d_fake_loss
+        d_loss.backward()
+        m.d_optimizer.step()                                                # :437
+        tag = f"s{size}_b{B}"
+        record_step(f"{tag}/d", m, D, m.d_optimizer,
+                    {"d_loss": d_loss.item(), "d_loss_real": d_real_loss.item(), "d_loss_fake": d_fake_loss.item(),
+                     "d_real_mean": d_real_output.mean().item(), "d_fake_mean": d_fake_output.mean().item()}, out)
+        m.g_optimizer.zero_grad()                                           # :440
+        d_output_for_g = D(fake_images)                                     # :442
+        g_loss = crit(d_output_for_g, real_labels)                          # :443
+        g_loss.backward()
+        m.g_optimizer.step()                                                # :446
+        tap.close()
+        record_step(f"{tag}/g", m, G, m.g_optimizer, {"g_loss": g_loss.item(), "g_fake_mean": d_output_for_g.mean().item()},
+                    out, extra_buffers=True)
+        nb = 4 if size == 64 else 5
+        assert len(tap.masks) == 3 * nb
+        out[f"{tag}/masks"] = I.pack_masks(tap.masks)
+    out["meta"] = np.array(json.dumps({"torch": torch.__version__, "threads": torch.get_num_threads(), "label_smoothing": 0.9,
+                                       "seeds": dict(z=SEED_Z, real=SEED_REAL, torch=SEED_TORCH + 5)}))
+    path = os.path.join(HERE, "golden_ablation_step.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def checkpoint_manifests():
     """(ix) structure of the two checkpoint layouts (keys, shapes, dtypes) -- no weights."""
     man = {}
@@ -316,6 +363,9 @@ if __name__ == "__main__":
     if "--spectral-norm" in sys.argv:
         make_spectral_norm()
         sys.exit(0)
+    if "--ablation" in sys.argv:
+        make_ablation_step()
+        sys.exit(0)
     if "--case" in sys.argv:                      # one more fixture: --case SIZE LATENT BATCH
         k = sys.argv.index("--case")
         make(int(sys.argv[k + 1]), int(sys.argv[k + 2]), int(sys.argv[k + 3]), full_image=False)
@@ -326,4 +376,5 @@ if __name__ == "__main__":
     make(128, 128, 32, full_image=False)
     make(64, 100, 128, full_image=False)          # BASELINE configs[3]: conv G/D 64x64, batch 128
     make_spectral_norm()
+    make_ablation_step()
     checkpoint_manifests()

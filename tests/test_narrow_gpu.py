@@ -40,8 +40,10 @@ TORCH_T = {"bf16": torch.bfloat16, "f16": torch.float16}
 TOL_FP32 = {"bf16": dict(metric=2.5e-2, image=1.5e-2, grad_t=0.5, grad_all=0.3, bn=2e-3),
             "f16": dict(metric=1.5e-3, image=2e-3, grad_t=0.6, grad_all=0.12, bn=3e-4)}
 # (2) vs the storage-rounding oracle with shared sign decisions: 8x apart, as the precisions are.
-TOL_Q = {"bf16": dict(metric=1.5e-2, image=6e-3, grad_t=3e-2, grad_all=2e-2, bn=1e-4),
-         "f16": dict(metric=2e-3, image=1.2e-3, grad_t=5e-3, grad_all=2.5e-3, bn=2e-5)}
+# (bn: ONE pre-BatchNorm element that rounds the other way moves a 4-sample feature variance by ~1 ulp / 4: the bound is one
+# such element, not the ~1e-6 the statistics agree to otherwise)
+TOL_Q = {"bf16": dict(metric=1.5e-2, image=6e-3, grad_t=3e-2, grad_all=2e-2, bn=8e-4),
+         "f16": dict(metric=2e-3, image=1.2e-3, grad_t=5e-3, grad_all=2.5e-3, bn=1e-4)}
 # sign decisions that may differ between the HIP path and the Quant oracle: at most this fraction of a layer's elements,
 # each with |pre-activation| below this fraction of the layer's largest
 SIGN_FRAC, SIGN_DIST = {"bf16": 5e-3, "f16": 8e-4}, {"bf16": 1.5e-2, "f16": 2.5e-3}

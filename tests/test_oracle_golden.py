@@ -126,3 +126,23 @@ def test_param_counts_match_reference_manifest():
         assert list(ref_d) == list(ds)
         for k, (shape, _) in ds.items():
             assert ref_d[k]["tensor"] == list(shape), k
+
+
+@pytest.mark.parametrize("size,latent,batch", [(64, 100, 8), (128, 128, 4)])
+def test_ablation_step(size, latent, batch):
+    """The oracle's restatement of AblationGANTrainer.train_epoch's iteration (ablation_vanilla_gan_signatures.py:397-467)
+    against the fixture replayed on the reference's own modules (tests/golden/make_golden.py::make_ablation_step)."""
+    import os
+    from common import GOLDEN, d_chans
+    f = np.load(os.path.join(GOLDEN, "golden_ablation_step.npz"))
+    tag = f"s{size}_b{batch}"
+    chans = d_chans(size) * 3
+    masks = [torch.from_numpy(m) for m in I.unpack_masks(f[f"{tag}/masks"], batch, chans)]
+    nb = len(masks) // 3
+    z = torch.from_numpy(I.gen_z(batch, latent, SEED["z"]))
+    real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
+    g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=True)
+    met, d_grads, g_grads = O.ablation_step(g_sd, d_sd, g_opt, d_opt, real, z, masks[:nb], masks[nb:2 * nb], masks[2 * nb:], size)
+    _check_step(f, f"{tag}/d", d_opt.names, {k: v for k, v in met.items() if k.startswith("d_")}, d_grads, d_sd, d_opt)
+    bufs = [k for k in g_sd if k not in g_opt.names]
+    _check_step(f, f"{tag}/g", g_opt.names, {k: v for k, v in met.items() if k.startswith("g_")}, g_grads, g_sd, g_opt, bufs)
