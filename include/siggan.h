@@ -77,6 +77,11 @@ typedef struct siggan_config {
     float   f16_grad_scale; /* F16 only: power-of-two factor carried by the backward chains so that small activation
                              * gradients stay above the fp16 subnormals; removed again inside the optimiser step (the bound
                              * *_grads arenas hold scale x gradient between *_grads and *_apply).  0 = default (1024). */
+    int32_t spectral_norm;  /* != 0: torch.nn.utils.spectral_norm on every Discriminator conv and on the classifier
+                             * (Discriminator(use_spectral_norm=True), discriminator_vanilla_gan.py:60-62,200-202): the d_params
+                             * arena then holds weight_orig, siggan_storage.d_sn_u / d_sn_v the weight_u / weight_v buffers; every
+                             * training-mode Discriminator forward runs one power iteration (u, v updated in place), every forward
+                             * divides the weights by sigma = u . (W v), and the D step's gradients flow through sigma. */
 } siggan_config;
 enum { SIGGAN_DTYPE_F32 = 0, SIGGAN_DTYPE_BF16 = 1, SIGGAN_DTYPE_F16 = 2 };
 
@@ -90,6 +95,9 @@ typedef struct siggan_storage {
     float *g_bn_running_mean, *g_bn_running_var;
     int64_t *g_bn_batches;
     float *d_params, *d_grads, *d_exp_avg, *d_exp_avg_sq, *d_adam_steps;
+    /* spectral norm only (else NULL): weight_u of all layers (conv blocks in order, then the classifier) concatenated --
+     * sizes Cout_l, 1 -- and weight_v likewise -- sizes Cin_l*16, 512*16 (siggan_sn_count) */
+    float *d_sn_u, *d_sn_v;
 } siggan_storage;
 
 /* Optimiser / loss hyper-parameters of one step (vanilla_gan_model.py:60-72,
@@ -122,6 +130,7 @@ int32_t siggan_param_tensors(const siggan_ctx *ctx, int which);        /* number
 /* offset (in floats) and element count of parameter tensor `idx` inside the flat arena */
 int siggan_param_span(const siggan_ctx *ctx, int which, int32_t idx, int64_t *offset, int64_t *numel);
 int64_t siggan_bn_count(const siggan_ctx *ctx);                        /* floats in g_bn_running_* */
+int64_t siggan_sn_count(const siggan_ctx *ctx, int which);             /* floats in d_sn_u (which = 0) / d_sn_v (1) */
 int32_t siggan_bn_layers(const siggan_ctx *ctx);
 int64_t siggan_workspace_bytes(const siggan_ctx *ctx);
 

@@ -367,6 +367,75 @@ def g_step(g_sd, d_sd, g_opt: AdamState, z, size, lr=2e-4, beta1=0.5, beta2=0.99
     return metrics, grads
 
 
+# --------------------------------------------------------------------------------------
+# spectral normalisation (torch.nn.utils.spectral_norm on every D conv + the classifier,
+# discriminator_vanilla_gan.py:60-62,200-202)
+# --------------------------------------------------------------------------------------
+SN_EPS = 1e-12
+
+
+def sn_weights(d_sd, sn: Dict[str, Tensor], size: int, training: bool) -> Dict[str, Tensor]:
+    """What torch's spectral-norm hook does before one Discriminator forward, for every conv and the classifier: in
+    training mode one power iteration on the stored (u, v) -- v = normalize(W^T u), u = normalize(W v), in place, no
+    gradient -- then in every mode sigma = u . (W v) and weight = weight_orig / sigma, differentiable w.r.t. weight_orig
+    (u, v constants).  ``d_sd`` holds weight_orig under the plain '<layer>.weight' keys (leaf tensors when gradients are
+    wanted); ``sn`` holds '<layer>.weight_u' / '<layer>.weight_v' and is updated in place.  Returns the dict to run the
+    Discriminator with."""
+    out = dict(d_sd)
+    for k in [k for k in d_sd if k.endswith(".weight")]:
+        base = k[:-len("weight")]
+        w = d_sd[k]
+        wm = w.reshape(w.shape[0], -1)
+        u, v = sn[base + "weight_u"], sn[base + "weight_v"]
+        if training:
+            with torch.no_grad():
+                v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=SN_EPS)
+                u = F.normalize(torch.mv(wm, v), dim=0, eps=SN_EPS)
+            sn[base + "weight_u"], sn[base + "weight_v"] = u, v
+        sigma = torch.dot(u, torch.mv(wm, v))
+        out[k] = w / sigma
+    return out
+
+
+def d_step_sn(g_sd, d_sd, sn, d_opt: AdamState, real, z, masks_real, masks_fake, size,
+              lr=2e-4, beta1=0.5, beta2=0.999, label_smoothing=0.9, dropout: float = 0.25):
+    """train_discriminator_step with Discriminator(use_spectral_norm=True) (vanilla_gan_model.py:180-252): D.train(), so the real
+    and the fake forward each run a power iteration and see different effective weights; the gradient w.r.t. weight_orig goes
+    through both sigmas."""
+    names = param_names(d_state_specs(size, real.shape[1]))
+    leaf = _leafs(d_sd, names)
+    with torch.no_grad():
+        fake = g_forward(g_sd, z, training=False, size=size)
+    real_preds = d_forward(sn_weights(leaf, sn, size, True), real, size, masks_real, dropout)
+    fake_preds = d_forward(sn_weights(leaf, sn, size, True), fake, size, masks_fake, dropout)
+    loss_real, loss_fake = bce(real_preds, label_smoothing), bce(fake_preds, 0.0)
+    loss = loss_real + loss_fake
+    gl = torch.autograd.grad(loss, [leaf[k] for k in names])
+    grads = {k: g.detach() for k, g in zip(names, gl)}
+    d_opt.apply(d_sd, grads, lr, beta1, beta2)
+    metrics = {"d_loss": float(loss.detach()), "d_loss_real": float(loss_real.detach()), "d_loss_fake": float(loss_fake.detach()),
+               "d_real_mean": float(real_preds.detach().mean()), "d_fake_mean": float(fake_preds.detach().mean())}
+    return metrics, grads
+
+
+def g_step_sn(g_sd, d_sd, sn, g_opt: AdamState, z, size, lr=2e-4, beta1=0.5, beta2=0.999):
+    """train_generator_step against a spectral-norm Discriminator (vanilla_gan_model.py:254-306): D.eval() -- no power
+    iteration, sigma from the stored (u, v)."""
+    names = param_names(g_state_specs(z.shape[1], size))
+    leaf = dict(g_sd)
+    leaf.update(_leafs(g_sd, names))
+    fake = g_forward(leaf, z, training=True, size=size)
+    for k in g_sd:
+        if k not in names:
+            g_sd[k] = leaf[k]
+    fake_preds = d_forward(sn_weights(d_sd, sn, size, False), fake, size, None)
+    loss = bce(fake_preds, 1.0)
+    gl = torch.autograd.grad(loss, [leaf[k] for k in names])
+    grads = {k: g.detach() for k, g in zip(names, gl)}
+    g_opt.apply(g_sd, grads, lr, beta1, beta2)
+    return {"g_loss": float(loss.detach()), "g_fake_mean": float(fake_preds.detach().mean())}, grads
+
+
 def ablation_step(g_sd, d_sd, g_opt: AdamState, d_opt: AdamState, real, z, masks_real, masks_fake, masks_g, size,
                   lr_g=2e-4, lr_d=2e-4, beta1=0.5, beta2=0.999, label_smoothing=0.9, dropout: float = 0.25, q=None):
     """One iteration of AblationGANTrainer.train_epoch (ablation_vanilla_gan_signatures.py:397-467), for the standard

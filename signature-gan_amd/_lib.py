@@ -21,7 +21,8 @@ METRIC_INDEX = {"d_loss": 0, "d_loss_real": 1, "d_loss_fake": 2, "d_real_mean": 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("latent_dim", C.c_int32), ("image_size", C.c_int32),
                 ("image_channels", C.c_int32), ("max_batch", C.c_int32), ("dropout", C.c_float),
-                ("leaky_slope", C.c_float), ("seed", C.c_uint64), ("dtype", C.c_int32), ("f16_grad_scale", C.c_float)]
+                ("leaky_slope", C.c_float), ("seed", C.c_uint64), ("dtype", C.c_int32), ("f16_grad_scale", C.c_float),
+                ("spectral_norm", C.c_int32)]
 
 
 DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
@@ -30,7 +31,8 @@ DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2,
 class Storage(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "g_params", "g_grads", "g_exp_avg", "g_exp_avg_sq", "g_adam_steps", "g_bn_running_mean",
-        "g_bn_running_var", "g_bn_batches", "d_params", "d_grads", "d_exp_avg", "d_exp_avg_sq", "d_adam_steps")]
+        "g_bn_running_var", "g_bn_batches", "d_params", "d_grads", "d_exp_avg", "d_exp_avg_sq", "d_adam_steps",
+        "d_sn_u", "d_sn_v")]
 
 
 class Hyper(C.Structure):
@@ -49,6 +51,7 @@ _SIGNATURES = {
     "siggan_param_span": (C.c_int, [_P, C.c_int, _I32, C.POINTER(_I64), C.POINTER(_I64)]),
     "siggan_bn_count": (_I64, [_P]),
     "siggan_bn_layers": (_I32, [_P]),
+    "siggan_sn_count": (_I64, [_P, C.c_int]),
     "siggan_workspace_bytes": (_I64, [_P]),
     "siggan_bind": (C.c_int, [_P, C.POINTER(Storage)]),
     "siggan_params_changed": (C.c_int, [_P]),

@@ -71,9 +71,10 @@ class EngineBacked(nn.Module):
     def _attach(self, engine, copy_in=True):
         """Re-point every parameter / buffer at its view inside ``engine``'s arenas."""
         views = dict(engine.views(self.which))
-        gviews = engine.views(self.which, "grads")
+        gviews = dict(engine.views(self.which, "grads"))
         if self.which == "g":
             views.update(engine.bn_views())
+        views, gviews = self._remap_views(engine, views, gviews)
         mods = dict(self.named_modules())
         with torch.no_grad():
             for name, t in list(self._named_leaves()):
@@ -90,6 +91,10 @@ class EngineBacked(nn.Module):
                     m._buffers[leaf] = v
         self._engine = engine
         engine.params_changed()
+
+    def _remap_views(self, engine, views, gviews):
+        """Hook: modules whose state_dict keys differ from the engine's (spectral norm) rename / add views here."""
+        return views, gviews
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
@@ -141,8 +146,12 @@ class EngineAdam(torch.optim.Adam):
             return eng
         w = self._module.which
         m, v = eng.views(w, "exp_avg"), eng.views(w, "exp_avg_sq")
-        steps = getattr(eng, f"{w}_adam_steps")
+        steps_flat = getattr(eng, f"{w}_adam_steps")
+        order = list(m)                                       # the engine's tensor order (index into *_adam_steps)
+        ename = getattr(self._module, "_engine_name", lambda n: n)
         names = [n for n, _ in self._module.named_parameters()]
+        m = {n: m[ename(n)] for n in names}; v = {n: v[ename(n)] for n in names}
+        steps = [steps_flat[order.index(ename(n))] for n in names]
         old = {n: self.state.get(p) for n, p in zip(names, self._module.parameters())}
         self.state.clear()
         with torch.no_grad():

@@ -225,17 +225,18 @@ __device__ __forceinline__ s16x4 tr_read(const unsigned short* M, int ld, int kb
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
 }
 
-template <class T, int BM, int BN, int WM, int WN>
+// BKP = pixels per K-tile (64: four MFMA k-steps per barrier)
+template <class T, int BM, int BN, int WM, int WN, int BKP>
 __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
     typedef typename Mma<T>::V Frag;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     // row stride = 64 bytes mod 256: the four k-rows of a transposing read then sit on disjoint bank quarters
     constexpr int LDA = BM == 32 ? 32 : BM + 32, LDB = BN == 32 ? 32 : BN + 32;
-    constexpr int CA = BM / 8, RA = 256 / CA, PA = BK / RA > 0 ? BK / RA : 1;     // 16-byte chunks per k-row, k-rows per pass
-    constexpr int CB = BN / 8, RB = 256 / CB, PB = BK / RB > 0 ? BK / RB : 1;
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BK * (LDA + LDB)];
+    constexpr int CA = BM / 8, RA = 256 / CA, PA = BKP / RA > 0 ? BKP / RA : 1;     // 16-byte chunks per k-row, k-rows per pass
+    constexpr int CB = BN / 8, RB = 256 / CB, PB = BKP / RB > 0 ? BKP / RB : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BKP * (LDA + LDB)];
     unsigned short* const sA = smem;
-    unsigned short* const sB = smem + 2 * BK * LDA;
+    unsigned short* const sB = smem + 2 * BKP * LDA;
     const T* const S = reinterpret_cast<const T*>(a.S);
     const T* const L = reinterpret_cast<const T*>(a.L);
     const T* const zeros = reinterpret_cast<const T*>(a.zeros);
@@ -248,18 +249,18 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
     const int i0 = (blockIdx.x / tiles_n) * BM, j0 = (blockIdx.x % tiles_n) * BN;
     const int kbeg = blockIdx.z * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
-    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int nk = (kend - kbeg + BKP - 1) / BKP;
     const int Hs = 1 << a.lgHs, Ws = 1 << a.lgWs, Hl = 2 * Hs, Wl = 2 * Ws, Cl = 1 << a.lgCl;
 
-    const int ca = tid % CA, ka = (tid / CA) & (BK - 1);
-    const int cb = tid % CB, kb = (tid / CB) & (BK - 1);
+    const int ca = tid % CA, ka = (tid / CA) % BKP;
+    const int cb = tid % CB, kb = (tid / CB) % BKP;
     const int jj = j0 + cb * 8, tap = jj >> a.lgCl, lch = jj & (Cl - 1);
     const int kh = tap >> 2, kw = tap & 3;
 
     s16x8 ra[PA], rb[PB];
 #define WG_LOAD_TILE(KT)                                                                              \
     {                                                                                                 \
-        const int kbase = kbeg + (KT) * BK;                                                           \
+        const int kbase = kbeg + (KT) * BKP;                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                              \
             const int pix = kbase + ka + RA * p;                                                      \
             const T* src = pix < kend ? S + ((size_t)pix * a.Cs + i0 + ca * 8) : zeros;               \
@@ -277,9 +278,9 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
 #define WG_STORE_TILE(BUF)                                                                            \
     {                                                                                                 \
         _Pragma("unroll") for (int p = 0; p < PA; ++p)                                                \
-            *reinterpret_cast<s16x8*>(sA + (BUF) * BK * LDA + (ka + RA * p) * LDA + ca * 8) = ra[p]; \
+            *reinterpret_cast<s16x8*>(sA + (BUF) * BKP * LDA + (ka + RA * p) * LDA + ca * 8) = ra[p]; \
         _Pragma("unroll") for (int p = 0; p < PB; ++p)                                                \
-            *reinterpret_cast<s16x8*>(sB + (BUF) * BK * LDB + (kb + RB * p) * LDB + cb * 8) = rb[p]; \
+            *reinterpret_cast<s16x8*>(sB + (BUF) * BKP * LDB + (kb + RB * p) * LDB + cb * 8) = rb[p]; \
     }
 
     f32x16 acc[TM][TN];
@@ -297,22 +298,23 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
     }
     __syncthreads();
     // column sums of S (bias gradient) in the first column tile, as in the fp32 kernel
-    constexpr int NQ = 256 / BM, KQ = BK / NQ;
+    constexpr int NQ = 256 / BM, KQ = BKP / NQ;
     const bool bias_blk = a.db != nullptr && j0 == 0;
     const int bcol = tid % BM, kq = tid / BM;
     float bsum = 0.f;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        const unsigned short* tA = sA + buf * BK * LDA;
-        const unsigned short* tB = sB + buf * BK * LDB;
+        const unsigned short* tA = sA + buf * BKP * LDA;
+        const unsigned short* tB = sB + buf * BKP * LDB;
         if (bias_blk) {
             const T* col = reinterpret_cast<const T*>(tA) + kq * KQ * LDA + bcol;
 #pragma unroll
             for (int k = 0; k < KQ; ++k) bsum += (float)col[k * LDA];
         }
-        Frag fa[2][TM], fb[2][TN];
+        constexpr int NS = BKP / 16;
+        Frag fa[NS][TM], fb[NS][TN];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const s16x4 lo = tr_read(tA, LDA, 16 * s, wm * (32 * TM) + 32 * i, lane);
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
             }
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
 }
 
 void launch_wgrad16(bool small, const WgradArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-#define WG16(T, BM, BN, WM, WN) hipExtLaunchKernelGGL((k_wgrad16<T, BM, BN, WM, WN>), grid, dim3(256), 0, st, e0, e1, 0, a)
+#define WG16(T, BM, BN, WM, WN) hipExtLaunchKernelGGL((k_wgrad16<T, BM, BN, WM, WN, 64>), grid, dim3(256), 0, st, e0, e1, 0, a)
     if (a.dt == DT_BF16) { if (small) WG16(bf16_t, 32, 128, 1, 4); else WG16(bf16_t, 64, 64, 2, 2); }
     else                 { if (small) WG16(f16_t, 32, 128, 1, 4); else WG16(f16_t, 64, 64, 2, 2); }
 #undef WG16

@@ -31,10 +31,12 @@ void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, 
 void launch_tick(DevState* st, hipStream_t s);
 
 // ---- fused "prepare" pass: every weight re-pack / BN-eval fold of one network in ONE launch -----
-enum PrepType : int { PREP_PACK_DOWN = 0, PREP_PACK_UP, PREP_FC_T, PREP_CLS, PREP_BN_EVAL };
+enum PrepType : int { PREP_PACK_DOWN = 0, PREP_PACK_UP, PREP_FC_T, PREP_CLS, PREP_BN_EVAL, PREP_SCALE };
 struct PrepJob {
     int type, O, I, perm;        // PACK_*: (O,I) channel counts; FC_T: O=K, I=C0; CLS: O=C; BN_EVAL: O=C, perm=perm_c0
     int dt;                      // PACK_DOWN / PACK_UP: element type of dst (DT_F32 / DT_BF16 / DT_F16); fp32 for the rest
+    const float* mul;            // PACK_* / CLS / SCALE: optional device scalar every weight is multiplied by (1 / sigma of a
+                                 // spectrally normalised layer); SCALE: dst[i] = src[i] * mul over O elements (fp32 copy)
     const float* src;            // weights (torch layout) / gamma
     const float* src2;           // beta
     const float* src3;           // running_mean
@@ -118,6 +120,32 @@ void launch_cls_bwd(int dt, const float* logits, int n0, float y0, float y1, con
 void launch_cls_wgrad(int dt, const float* dlogit, const void* act, float* dWc, float* dbc, int B, int C, hipStream_t s);
 // dst[i] = (float)src[i] for a tensor of element type dt
 void launch_to_f32(int dt, const void* src, float* dst, int64_t n, hipStream_t s);
+
+// ---- spectral normalisation of the Discriminator (sn.hip) -------------------------------------------------------------
+struct SnLayer {
+    const float* W;              // weight_orig in the parameter arena, (rows, K) row-major = weight.view(Cout, -1)
+    int rows, K;
+    int u_off, v_off;            // offsets of this layer's u / v inside the flat u / v arenas (and of tbuf / wbuf)
+    int64_t w_off;               // offset of the weight tensor inside the gradient arena
+};
+struct SnTable {
+    static constexpr int MAXS = 8;          // conv blocks + classifier
+    int n;
+    SnLayer layer[MAXS];
+    int pre_k[MAXS + 1], pre_r[MAXS + 1];   // prefix sums of ceil(K / 256) and ceil(rows / 4): workgroups of k_sn_wtu / k_sn_wv
+    float *u, *v;                           // the caller's weight_u / weight_v buffers (flat, layer order)
+    float *tbuf, *wbuf;                     // scratch: W^T u (v-sized), W v (u-sized)
+    float* sig;                             // [3 slots][sigma | 1/sigma][MAXS]
+    float *u_saved, *v_saved;               // [3 slots][u_total] / [3 slots][v_total]: each pass's (u, v)
+    float* dots;                            // [2 passes][MAXS][64] partial <G_p, W>
+    int u_total, v_total;
+    int slot[2];                            // k_sn_combine: the sigma slot of pass 0 / pass 1
+};
+// sigma (+ one power iteration when training) of every layer for one pass, results into slot
+void launch_sn_sigma(const SnTable& t, int training, int slot, float eps, hipStream_t s);
+// out[arena] = sum over passes of the gradient w.r.t. weight_orig (through sigma) from the per-pass gradients w.r.t. the
+// normalised weights g0 / g1 (whole-arena temporaries; non-weight entries are added plainly)
+void launch_sn_combine(const SnTable& t, const float* g0, const float* g1, float* out, int64_t total, int npass, hipStream_t s);
 
 // ---- optimiser ------------------------------------------------------------------------------
 // reads steps[0], writes steps[i] += 1 for every tensor, derives the Adam scalars; with

@@ -72,6 +72,7 @@ static long long prep_units(const PrepJob& j) {
         case PREP_PACK_DOWN: case PREP_CLS: return j.type == PREP_CLS ? 1 : j.O;
         case PREP_PACK_UP: return j.O;
         case PREP_FC_T: return (long long)(j.I * 16 / 64) * ((j.O + 127) / 128);
+        case PREP_SCALE: return (j.O + 1023) / 1024;
         default: return (j.O + 255) / 256;
     }
 }
@@ -84,6 +85,7 @@ void prep_add(PrepTable& t, const PrepJob& j, long long /*count*/) {
 }
 // a packed weight goes out in the element type the consuming kernel reads (q.dt: fp32, or bf16 / f16 rounded to nearest)
 __device__ __forceinline__ void put_w(const PrepJob& q, size_t idx, float v) {
+    if (q.mul) v *= q.mul[0];
     if (q.dt == DT_F32) q.dst[idx] = v;
     else if (q.dt == DT_BF16) reinterpret_cast<bf16_t*>(q.dst)[idx] = (bf16_t)v;
     else reinterpret_cast<f16_t*>(q.dst)[idx] = (f16_t)v;
@@ -120,6 +122,9 @@ __global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
         }
         __syncthreads();
         for (int e = tid; e < 64 * kn; e += 256) { const int k = e >> 6, r = e & 63; q.dst[(size_t)(k0 + k) * F + f0 + r] = tile[r * 129 + k]; }
+    } else if (q.type == PREP_SCALE) {           // dst = src * mul (fp32), 1024 elements per unit
+        const float m = q.mul ? q.mul[0] : 1.0f;
+        for (int e = u * 1024 + tid; e < min(q.O, (u + 1) * 1024); e += 256) q.dst[e] = q.src[e] * m;
     } else {                                     // BN eval: [scale | shift | mean | rstd]
         const int C = q.O, c = u * 256 + tid;
         if (c < C) {

@@ -118,6 +118,9 @@ struct siggan_ctx {
     int S, latent, Lg, Ld, Bm;
     int dt;             // element type of the activation / gradient tensors and of the MFMA weight packs (act.h)
     size_t es;          // its size in bytes
+    bool sn;            // spectral normalisation of every Discriminator weight (sn.hip)
+    SnTable snt;        // its layer table (pointers into the bound arenas are refreshed by siggan_bind)
+    float *sn_tbuf, *sn_wbuf, *sn_sig, *sn_us, *sn_vs, *sn_dots, *sn_g[2], *d_w1s;
     int variant;        // SIGGAN_STEP_TRAINER / SIGGAN_STEP_ABLATION (siggan_set_step_variant)
     bool abl_masks;     // ablation step: the D half was given explicit masks, the third set waits in mask_stage for the G half
     bool fc_fused;      // Generator.fc runs as the one-launch MFMA kernels of fc.hip (max_batch <= 256, latent % 4 == 0)
@@ -244,6 +247,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     c->dt = cfg->dtype; c->es = dt_size(c->dt);
     c->fc_fused = cfg->max_batch <= 256 && (cfg->latent_dim & 3) == 0;
     c->variant = SIGGAN_STEP_TRAINER; c->abl_masks = false;
+    c->sn = cfg->spectral_norm != 0;
     // fp16 stores activation gradients of order 1e-7..1e-3: a power-of-two scale (exact to apply and to remove) lifts
     // them clear of the fp16 subnormals; bf16 has fp32's exponent range and needs none
     c->gscale = c->dt == DT_F16 ? (cfg->f16_grad_scale > 0.f ? cfg->f16_grad_scale : 1024.f) : 1.0f;
@@ -306,6 +310,16 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->real_stage, Bm * c->S * c->S);
         carve(&c->real_next, Bm * c->S * c->S);
         { int64_t sumC = 0; for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l]; carve(&c->mask_stage, 3 * Bm * sumC); }
+        if (c->sn) {
+            int64_t ut = 1, vt = (int64_t)c->dC[c->Ld] * 16;
+            for (int l = 1; l <= c->Ld; ++l) { ut += c->dC[l]; vt += (int64_t)c->dC[l - 1] * 16; }
+            carve(&c->sn_tbuf, vt); carve(&c->sn_wbuf, ut);
+            carve(&c->sn_sig, 3 * 2 * SnTable::MAXS);
+            carve(&c->sn_us, 3 * ut); carve(&c->sn_vs, 3 * vt);
+            carve(&c->sn_dots, 2 * SnTable::MAXS * 64);
+            carve(&c->sn_g[0], c->d_total); carve(&c->sn_g[1], c->d_total);
+            carve(&c->d_w1s, (int64_t)c->dC[1] * 16);
+        }
         carve(&c->metrics, SIGGAN_M_COUNT);
         carve_t(&c->op_pack, (int64_t)512 * 512 * 16);
         carve(&c->zeros, 64);
@@ -375,6 +389,12 @@ extern "C" int siggan_param_span(const siggan_ctx* c, int which, int32_t idx, in
     return SIGGAN_OK;
 }
 extern "C" int64_t siggan_bn_count(const siggan_ctx* c) { return c ? c->bn_total : -1; }
+extern "C" int64_t siggan_sn_count(const siggan_ctx* c, int which) {
+    if (!c) return -1;
+    int64_t ut = 1, vt = (int64_t)c->dC[c->Ld] * 16;
+    for (int l = 1; l <= c->Ld; ++l) { ut += c->dC[l]; vt += (int64_t)c->dC[l - 1] * 16; }
+    return which == 0 ? ut : vt;
+}
 extern "C" int32_t siggan_bn_layers(const siggan_ctx* c) { return c ? c->Lg + 1 : -1; }
 extern "C" int64_t siggan_workspace_bytes(const siggan_ctx* c) { return c ? (int64_t)c->ws_bytes : -1; }
 
@@ -402,6 +422,25 @@ extern "C" int siggan_bind(siggan_ctx* c, const siggan_storage* st) {
     for (const void* p : all)
         if (((uintptr_t)p & 15) != 0) return fail(SIGGAN_E_INVALID, "siggan_bind: arenas must be 16-byte aligned");
     c->st = *st;
+    if (c->sn) {
+        if (!st->d_sn_u || !st->d_sn_v) return fail(SIGGAN_E_INVALID, "siggan_bind: a spectral-norm context needs d_sn_u / d_sn_v");
+        SnTable& t = c->snt; memset(&t, 0, sizeof t);
+        t.n = c->Ld + 1;
+        int uo = 0, vo = 0;
+        t.pre_k[0] = t.pre_r[0] = 0;
+        for (int i = 0; i < t.n; ++i) {
+            SnLayer& L = t.layer[i];
+            const bool cls = i == c->Ld;
+            const int pi = cls ? di_cls_w(c) : di_w(i + 1);
+            L.W = st->d_params + c->d_off[pi]; L.w_off = c->d_off[pi];
+            L.rows = cls ? 1 : c->dC[i + 1]; L.K = cls ? c->dC[c->Ld] * 16 : c->dC[i] * 16;
+            L.u_off = uo; L.v_off = vo; uo += L.rows; vo += L.K;
+            t.pre_k[i + 1] = t.pre_k[i] + (L.K + 255) / 256;
+            t.pre_r[i + 1] = t.pre_r[i] + (L.rows + 3) / 4;
+        }
+        t.u = st->d_sn_u; t.v = st->d_sn_v; t.tbuf = c->sn_tbuf; t.wbuf = c->sn_wbuf; t.sig = c->sn_sig;
+        t.u_saved = c->sn_us; t.v_saved = c->sn_vs; t.dots = c->sn_dots; t.u_total = uo; t.v_total = vo;
+    }
     c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0; c->staged_B = 0;
     drop_dreal(c);
     return SIGGAN_OK;
@@ -443,7 +482,7 @@ static int check_call(siggan_ctx* c, int batch, bool need_bound = true) {
 
 // One launch per network rebuilds everything derived from its arena: GEMM-friendly weight copies and
 // (for G) the BatchNorm eval-mode scale/shift tables.  sg / sd: the lanes the two launches go to.
-static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, bool do_d) {
+static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, bool do_d, int sn_slot = 0) {
     if (do_g) {
         PrepTable t; t.njobs = 0; t.overflow = 0;
         PrepJob j; memset(&j, 0, sizeof j);
@@ -478,6 +517,7 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
             const long long n = (long long)c->dC[l - 1] * c->dC[l] * 16;
             memset(&j, 0, sizeof j);
             j.src = DP(c, di_w(l)); j.dt = c->dt;                      // (Cout, Cin, 4, 4)
+            if (c->sn) j.mul = c->sn_sig + (sn_slot * 2 + 1) * SnTable::MAXS + (l - 1);   // W / sigma of this pass
             j.type = PREP_PACK_DOWN; j.O = c->dC[l]; j.I = c->dC[l - 1]; j.dst = (float*)c->d_dn[l];  // forward
             prep_add(t, j, n);
             j.type = PREP_PACK_UP; j.I = c->dC[l]; j.O = c->dC[l - 1]; j.dst = (float*)c->d_up[l];    // input-gradient: contract Cout
@@ -485,7 +525,14 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
         }
         memset(&j, 0, sizeof j);
         j.type = PREP_CLS; j.O = c->dC[c->Ld]; j.src = DP(c, di_cls_w(c)); j.dst = c->wcp;
+        if (c->sn) j.mul = c->sn_sig + (sn_slot * 2 + 1) * SnTable::MAXS + c->Ld;
         prep_add(t, j, (long long)c->dC[c->Ld] * 16);
+        if (c->sn) {                                                   // block 1 is not an MFMA kernel: an fp32 scaled copy
+            memset(&j, 0, sizeof j);
+            j.type = PREP_SCALE; j.O = c->dC[1] * 16; j.src = DP(c, di_w(1)); j.dst = c->d_w1s;
+            j.mul = c->sn_sig + (sn_slot * 2 + 1) * SnTable::MAXS;
+            prep_add(t, j, j.O);
+        }
         if (!launch_prepare(t, BN_EPS, sd)) c->lane_err = hipErrorInvalidValue;
     }
 }
@@ -583,7 +630,7 @@ static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool d
     const float slope = c->cfg.leaky_slope;
     auto act = [&](int l) { const int64_t H = c->S >> l; return c->d_a[l] + (size_t)((int64_t)r0 * H * H * c->dC[l]) * c->es; };
     auto nz = [&](int l) { return dropout ? c->d_noise[l] + (int64_t)r0 * c->dC[l] : nullptr; };
-    launch_conv1_fwd(c->dt, x, nB, x, DP(c, di_w(1)), DP(c, di_b(1)), nz(1), slope, act(1), nB, c->S, c->dC[1], s);
+    launch_conv1_fwd(c->dt, x, nB, x, c->sn ? c->d_w1s : DP(c, di_w(1)), DP(c, di_b(1)), nz(1), slope, act(1), nB, c->S, c->dC[1], s);
     for (int l = 2; l <= c->Ld; ++l) {
         const int Hi = c->S >> (l - 1), Ho = Hi / 2;
         GConvArgs a = gconv_args(c);
@@ -603,45 +650,53 @@ static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool d
 // block's d(pre-activation) and run beside the rest of the chain.
 struct BceSpec { int n0; float y0, y1; float* mt; int is_g; };   // rows < n0: target y0, the rest y1 (each segment's mean)
 
+// r0 / garena (spectral norm: one pass at a time): the Bd rows start at workspace row r0 and the gradients go to garena
+// (an arena-shaped temporary) instead of the bound arena.
 static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, const float* x1, int Bd, bool dropout,
-                            bool want_wgrad, bool want_dimage, const BceSpec& bce) {
+                            bool want_wgrad, bool want_dimage, const BceSpec& bce, int r0 = 0, float* garena = nullptr) {
     const float slope = c->cfg.leaky_slope;
     const int Ld = c->Ld;
+    float* const ga = garena ? garena : c->st.d_grads;
+    auto G_ = [&](int i) { return ga + c->d_off[i]; };
+    auto act = [&](int l) { const int64_t H = c->S >> l; return c->d_a[l] + (size_t)((int64_t)r0 * H * H * c->dC[l]) * c->es; };
+    auto dvp = [&](int l) { const int64_t H = c->S >> l; return c->d_dv[l] + (size_t)((int64_t)r0 * H * H * c->dC[l]) * c->es; };
+    auto nz = [&](int l) { return dropout ? c->d_noise[l] + (int64_t)r0 * c->dC[l] : nullptr; };
+    const float* const w1 = c->sn ? c->d_w1s : DP(c, di_w(1));
     // sigmoid + BCE: losses / means into the metrics, d(logit) for the classifier's weight gradient -- on lane b; the
     // chain below recomputes d(logit) from the logits and does not wait for it
     L.fork(L.b);
-    launch_bce(c->logits, Bd, bce.n0, bce.y0, bce.y1, c->probs, c->dlogit, bce.mt, bce.is_g, L.b, c->gscale);
-    launch_cls_bwd(c->dt, c->logits, bce.n0, bce.y0, bce.y1, c->wcp, c->d_a[Ld], dropout ? c->d_noise[Ld] : nullptr, slope, c->d_dv[Ld], Bd,
+    launch_bce(c->logits + r0, Bd, bce.n0, bce.y0, bce.y1, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, L.b, c->gscale);
+    launch_cls_bwd(c->dt, c->logits + r0, bce.n0, bce.y0, bce.y1, c->wcp, act(Ld), nz(Ld), slope, dvp(Ld), Bd,
                    c->dC[Ld], L.m, c->gscale);
     if (want_wgrad)
-        launch_cls_wgrad(c->dt, c->dlogit, c->d_a[Ld], DG(c, di_cls_w(c)), DG(c, di_cls_b(c)), Bd, c->dC[Ld], L.b);
+        launch_cls_wgrad(c->dt, c->dlogit + r0, act(Ld), G_(di_cls_w(c)), G_(di_cls_b(c)), Bd, c->dC[Ld], L.b);
     for (int l = Ld; l >= 2; --l) {
         const int Ho = c->S >> l, Hi = 2 * Ho, Co = c->dC[l], Ci = c->dC[l - 1];
         if (want_wgrad) {
             L.fork(L.a);                                   // d_dv[l] is complete on m here
             WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
-            w.S = c->d_dv[l]; w.L = c->d_a[l - 1]; w.slab = c->slab; w.dw = DG(c, di_w(l)); w.B = Bd; w.Cs = Co; w.Cl = Ci;
+            w.S = dvp(l); w.L = act(l - 1); w.slab = c->slab; w.dw = G_(di_w(l)); w.B = Bd; w.Cs = Co; w.Cl = Ci;
             w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
-            w.db = DG(c, di_b(l));                           // bias gradient = column sums of d(pre-activation): rides in the same kernel
+            w.db = G_(di_b(l));                              // bias gradient = column sums of d(pre-activation): rides in the same kernel
             const int max_splits = (int)(c->slab_floats / ((int64_t)Co * (16 * Ci + 1)));
             launch_wgrad(w, max_splits, L.a);
         }
         // input gradient ("up" form): contract Cout, produce Cin at (Hi x Hi); fused leaky'/dropout of block l-1
         GConvArgs a = gconv_args(c);
-        a.in = c->d_dv[l]; a.wp = c->d_up[l]; a.out = c->d_dv[l - 1];
+        a.in = dvp(l); a.wp = c->d_up[l]; a.out = dvp(l - 1);
         a.B = Bd; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
         a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 1; a.M = Bd * Ho * Ho;
-        a.epi = EPI_LRELU_BWD; a.aref = c->d_a[l - 1]; a.noise = dropout ? c->d_noise[l - 1] : nullptr; a.slope = slope;
+        a.epi = EPI_LRELU_BWD; a.aref = act(l - 1); a.noise = nz(l - 1); a.slope = slope;
         launch_gconv(a, L.m);
     }
     if (want_wgrad) {
         L.fork(L.b);
-        launch_conv1_wgrad(c->dt, c->d_dv[1], x0, n0, x1, DG(c, di_w(1)), DG(c, di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
+        launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
         L.join(L.a);
     }
     L.join(L.b);
     if (want_dimage)
-        launch_conv1_dgrad_tanh(c->dt, c->d_dv[1], DP(c, di_w(1)), x0, c->dpre, Bd, c->S, c->dC[1], L.m);
+        launch_conv1_dgrad_tanh(c->dt, dvp(1), w1, x0, c->dpre, Bd, c->S, c->dC[1], L.m);
 }
 
 // Backward through the Generator from d(pre-tanh) in c->dpre; fills the G gradient arena.  Lane m:
@@ -715,7 +770,43 @@ static int check_hyper(const siggan_hyper* hp) {
 // ------------------------------------------------------------------------------------------
 // the four step phases (inputs already staged in the workspace: c->real_stage, c->z, c->mask_stage)
 // ------------------------------------------------------------------------------------------
+static const float SN_EPS = 1e-12f;        // torch.nn.utils.spectral_norm's eps
+
+// D step with a spectrally normalised Discriminator: every training forward runs one power iteration, so the real and the
+// fake pass see different effective weights W / sigma_p.  The passes therefore run one after the other on the main lane
+// (sigma -> weight packs -> forward), the backward is done per pass with that pass's packs into two arena-shaped
+// temporaries, and k_sn_combine forms the gradient w.r.t. weight_orig through both sigmas.
+static void phase_d_grads_sn(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
+    const int B = k.B;
+    const bool drop = c->cfg.dropout > 0.f;
+    repack(c, L.m, L.m, k.g_dirty != 0, false);
+    if (k.pre_real)
+        L.note(hipMemcpyAsync(c->real_stage, c->real_next, (size_t)B * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, L.m));
+    if (drop) make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, 0, 2, L.m);
+    const float* fake = c->img;
+    if (k.variant == SIGGAN_STEP_ABLATION) {
+        g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, L.m, nullptr, nullptr, 2, c->z_g);
+        L.record(c->ev_gfwd, L.m);
+        fake = c->img_g;
+    } else {
+        g_forward_pass(c, k.has_z ? c->z : nullptr, B, false, c->img, L.m, nullptr, nullptr, 1, c->z);
+    }
+    launch_sn_sigma(c->snt, 1, 0, SN_EPS, L.m);                       // D(real): power iteration 1
+    repack(c, L.m, L.m, false, true, 0);
+    d_forward_rows(c, c->real_stage, 0, B, drop, L.m, c->slab_k);
+    launch_sn_sigma(c->snt, 1, 1, SN_EPS, L.m);                       // D(fake): power iteration 2
+    repack(c, L.m, L.m, false, true, 1);
+    d_forward_rows(c, fake, B, B, drop, L.m, c->slab_k);
+    launch_bce(c->logits, 2 * B, B, k.ls, 0.f, c->probs, c->dlogit, k.mt, 0, L.m, c->gscale);     // the step's metrics
+    d_backward_pass(c, L, fake, B, fake, B, drop, true, false, BceSpec{B, 0.f, 0.f, nullptr, 0}, B, c->sn_g[1]);
+    repack(c, L.m, L.m, false, true, 0);
+    d_backward_pass(c, L, c->real_stage, B, c->real_stage, B, drop, true, false, BceSpec{B, k.ls, k.ls, nullptr, 0}, 0, c->sn_g[0]);
+    c->snt.slot[0] = 0; c->snt.slot[1] = 1;
+    launch_sn_combine(c->snt, c->sn_g[0], c->sn_g[1], c->st.d_grads, c->d_total, 2, L.m);
+}
+
 static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
+    if (c->sn) return phase_d_grads_sn(c, L, k);
     const int B = k.B;
     const bool drop = c->cfg.dropout > 0.f;
     L.fork(L.a);                                                     // lane a: D's packs, dropout tables, D(real)
@@ -758,13 +849,14 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
 static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const int B = k.B;
     const float* zg; float* img;
+    const bool d_pack = !c->sn && k.d_dirty != 0;                    // (spectral norm: the packs follow sigma, below)
     if (k.spec_g) {                                                  // forward already enqueued by siggan_step_begin
-        repack(c, L.m, L.m, false, k.d_dirty != 0);
+        repack(c, L.m, L.m, false, d_pack);
         L.wait(L.m, c->ev_gfwd);
         zg = c->z_g; img = c->img_g;
     } else {
         L.fork(L.a);
-        repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
+        repack(c, L.m, L.a, k.g_dirty != 0, d_pack);
         g_forward_pass(c, k.has_z ? c->z : nullptr, B, true, c->img, L.m, nullptr, nullptr, 2, c->z);   // G.train(): BN batch stats (train...py:349)
         L.join(L.a);
         zg = c->z; img = c->img;
@@ -773,6 +865,10 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // fresh set of dropout masks -- and the target is the smoothed real label (ablation...py:441-442)
     const bool abl = k.variant == SIGGAN_STEP_ABLATION;
     const bool gdrop = abl && c->cfg.dropout > 0.f;
+    if (c->sn) {        // D.eval() (trainer step): sigma from the stored u, v; D.train() (ablation step): a third power iteration
+        launch_sn_sigma(c->snt, abl ? 1 : 0, 2, SN_EPS, L.m);
+        repack(c, L.m, L.m, false, true, 2);
+    }
     if (gdrop) {
         int64_t sumC = 0;
         for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l];
@@ -835,6 +931,7 @@ static int run_phase(siggan_ctx* c, const PhaseKey& k, hipStream_t u) {
     const bool overlap = (c->mode & SIGGAN_MODE_OVERLAP) != 0;
     const bool graph = (c->mode & SIGGAN_MODE_GRAPH) != 0 && g_prof == nullptr;
     if (graph && c->comm && k.phase >= 2) return fail(SIGGAN_E_STATE, "SIGGAN_MODE_GRAPH is not available with a communicator");
+    if (graph && c->sn) return fail(SIGGAN_E_STATE, "SIGGAN_MODE_GRAPH is not available with spectral normalisation");
     if (!graph) {
         Lanes L{c, u, overlap ? c->s_a : u, overlap ? c->s_b : u};
         run_phase_body(c, L, k);
@@ -914,8 +1011,8 @@ extern "C" int siggan_g_forward(siggan_ctx* c, const float* z_dev, int32_t batch
     if (!z_dev || !images_dev) return fail(SIGGAN_E_INVALID, "null tensor");
     hipStream_t s = (hipStream_t)stream;
     if ((rc = settle(c, s))) return rc;
-    repack(c, s, s, c->g_dirty, c->d_dirty);
-    c->g_dirty = c->d_dirty = false;
+    repack(c, s, s, c->g_dirty, !c->sn && c->d_dirty);
+    c->g_dirty = false; if (!c->sn) c->d_dirty = false;
     g_forward_pass(c, z_dev, batch, training != 0, images_dev, s);
     if (training) c->g_dirty = true;   // running statistics moved: the eval-mode tables are stale
     LAUNCHCHK();
@@ -931,7 +1028,8 @@ extern "C" int siggan_d_forward(siggan_ctx* c, const float* x_dev, int32_t batch
     hipStream_t s = (hipStream_t)stream;
     drop_dreal(c);                     // the activation rows of a D(real) forward started ahead of time are overwritten
     if ((rc = settle(c, s))) return rc;
-    repack(c, s, s, c->g_dirty, c->d_dirty);
+    if (c->sn) launch_sn_sigma(c->snt, training != 0, 2, SN_EPS, s);   // train(): one power iteration (u, v move), as torch's hook
+    repack(c, s, s, c->g_dirty, c->sn || c->d_dirty, 2);
     c->g_dirty = c->d_dirty = false;
     const bool drop = training != 0 && c->cfg.dropout > 0.f;
     if (drop) { if (!masks_dev) launch_tick(c->dev, s); make_noise(c, masks_dev, batch, 0, 1, s); }
@@ -1068,7 +1166,7 @@ extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, 
     c->abl_masks = false;
     // a staged next batch: start its D(real) forward beside this Generator backward (own lane: eager overlap mode only)
     k.pre_real = c->staged_B == B && c->dreal_B == 0 && (c->mode & SIGGAN_MODE_OVERLAP) != 0 && (c->mode & SIGGAN_MODE_GRAPH) == 0 &&
-                 g_prof == nullptr && c->pending == 0;
+                 g_prof == nullptr && c->pending == 0 && !c->sn;
     if ((rc = run_phase(c, k, s))) return rc;
     if (k.pre_real) c->dreal_B = B;
     c->g_fwd_pending = 0;

@@ -4,11 +4,10 @@ Mirrors Discriminator (discriminator_vanilla_gan.py:84-282): same constructor, `
 ``forward`` -> probabilities (B, 1), ``forward_features`` -> (B, 8192).
 
 Spectral normalisation (``use_spectral_norm=True``, :60-62, :200-202 -- ``torch.nn.utils.spectral_norm`` on every
-conv and on the classifier) is supported for INFERENCE: the module then carries the reference's SN keys
-(``weight_orig`` parameter, ``weight_u`` / ``weight_v`` buffers, 20 keys for the 64x64 net), and in ``eval()`` mode --
-where torch's hook runs no power iteration -- the engine is handed ``weight_orig / sigma``, sigma = u . (W v), so a
-checkpoint trained with the reference's ablation harness can be loaded and scored.  Training with SN (one power
-iteration per training forward, gradients through sigma) is not built: ``train()``-mode forward raises."""
+conv and on the classifier): the module carries the reference's SN keys (``weight_orig`` parameter, ``weight_u`` /
+``weight_v`` buffers, 20 keys for the 64x64 net) as views of the engine's storage, and the hook's arithmetic -- one power
+iteration per ``train()``-mode forward, ``weight_orig / sigma`` with sigma = u . (W v) in every forward, the D step's
+gradient through sigma -- runs inside the library (``csrc/sn.hip``)."""
 from typing import Tuple
 
 import torch
@@ -56,7 +55,6 @@ class Discriminator(EngineBacked):
         self.input_size, self.input_channels = input_size, input_channels
         self.use_spectral_norm, self.dropout, self.leaky_slope = use_spectral_norm, dropout, leaky_slope
         entries = layout.discriminator_entries(input_size, input_channels)
-        self._sn_seen = None
         if use_spectral_norm:
             build_tree(self, _sn_entries(entries), _sn_init)
         else:
@@ -64,44 +62,36 @@ class Discriminator(EngineBacked):
         if _engine is not None:
             if abs(_engine.dropout - dropout) > 1e-12 or abs(_engine.leaky_slope - leaky_slope) > 1e-12:
                 raise ValueError("shared engine was created with different dropout / leaky_slope")
+            if bool(_engine.spectral_norm) != bool(use_spectral_norm):
+                raise ValueError("shared engine was created with a different spectral_norm setting")
             self._shared_engine = True
             self._attach(_engine, copy_in=True)
 
+    # ---- spectral norm -------------------------------------------------------------------------------
+    # The module keeps the reference's keys (weight_orig parameter, weight_u / weight_v buffers); the engine keeps weight_orig in
+    # its parameter arena under the plain layer name and u / v in its own flat buffers.  All of torch's hook -- one power
+    # iteration per training forward, sigma = u . (W v), weight = weight_orig / sigma, the gradient through sigma -- runs
+    # inside the library (csrc/sn.hip).
+    @staticmethod
+    def _engine_name(name):
+        return name[:-len("_orig")] if name.endswith("weight_orig") else name
+
+    def _remap_views(self, engine, views, gviews):
+        if not self.use_spectral_norm:
+            return views, gviews
+        if not engine.spectral_norm:
+            raise ValueError("a spectral-norm Discriminator needs an Engine created with spectral_norm=True")
+        v2 = {(k + "_orig" if k.endswith(".weight") else k): t for k, t in views.items()}
+        g2 = {(k + "_orig" if k.endswith(".weight") else k): t for k, t in gviews.items()}
+        v2.update(engine.sn_views())
+        return v2, g2
+
     def _engine_kwargs(self):
-        return dict(image_size=self.input_size, dropout=self.dropout, leaky_slope=self.leaky_slope)
-
-    # ---- spectral norm (inference) -------------------------------------------------------------------
-    def _named_leaves(self):
-        """Leaves that live in the engine's arenas: with SN only the biases (weight_orig / u / v stay module tensors)."""
-        for name, t in super()._named_leaves():
-            if not (self.use_spectral_norm and name.endswith(_SN_SUFFIXES)):
-                yield name, t
-
-    def _sn_sync(self, eng):
-        """engine weight <- weight_orig / (u . (W v)), when weight_orig / u / v changed since the last call."""
-        sd = dict(self.named_parameters())
-        sd.update(dict(self.named_buffers()))
-        stamp = tuple((k, t.data_ptr(), t._version) for k, t in sd.items() if k.endswith(_SN_SUFFIXES))
-        if stamp == self._sn_seen:
-            return
-        views = eng.views("d")
-        with torch.no_grad():
-            for key, v in views.items():
-                if key.endswith(".weight"):
-                    base = key[:-len("weight")]
-                    w, u, vv = sd[base + "weight_orig"], sd[base + "weight_u"], sd[base + "weight_v"]
-                    sigma = torch.dot(u.to(v.device), torch.mv(w.to(v.device).reshape(w.shape[0], -1), vv.to(v.device)))
-                    v.copy_(w.to(v.device) / sigma)
-        eng.params_changed()
-        self._sn_seen = stamp
+        return dict(image_size=self.input_size, dropout=self.dropout, leaky_slope=self.leaky_slope,
+                    spectral_norm=self.use_spectral_norm)
 
     def _forward(self, x, want_features):
         eng = self._require_engine()
-        if self.use_spectral_norm:
-            if self.training:
-                raise NotImplementedError("spectral-norm training (power iteration + gradients through sigma) is not built "
-                                          "(SURVEY 8f-4); call .eval() to score with a spectral-norm checkpoint")
-            self._sn_sync(eng)
         return eng.d_forward(x, training=self.training, want_features=want_features)
 
     @torch.no_grad()

@@ -30,7 +30,7 @@ class Engine:
     no conversion)."""
 
     def __init__(self, latent_dim=100, image_size=64, max_batch=64, device="cuda:0", seed=0,
-                 dropout=0.25, leaky_slope=0.2, image_channels=1, dtype="f32", f16_grad_scale=0.0):
+                 dropout=0.25, leaky_slope=0.2, image_channels=1, dtype="f32", f16_grad_scale=0.0, spectral_norm=False):
         layout.check_size(image_size)
         if image_channels != 1:
             raise ValueError(f"only image_channels == 1 is built, got {image_channels}")
@@ -49,6 +49,9 @@ class Engine:
         self.dtype = {0: "f32", 1: "bf16", 2: "f16"}[_lib.DTYPES[str(dtype)]]
         self.act_dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[self.dtype]
         self.f16_grad_scale = float(f16_grad_scale)
+        # torch.nn.utils.spectral_norm on every Discriminator conv + the classifier (discriminator_vanilla_gan.py:60-62,200-202):
+        # d_params then holds weight_orig, d_sn_u / d_sn_v the weight_u / weight_v buffers
+        self.spectral_norm = bool(spectral_norm)
         self._h = None
         self._staged = None
         self._comm = None
@@ -74,12 +77,28 @@ class Engine:
         self.g_bn_mean, self.g_bn_var = z(bn_total), torch.ones(bn_total, dtype=torch.float32, device=dev)
         self.g_bn_batches = z(len(self.bn_spans), torch.int64)
         self.metrics = z(_lib.M_COUNT)
+        self.d_sn_u = self.d_sn_v = None
+        if self.spectral_norm:
+            # spans of weight_u (Cout) / weight_v (Cin*kh*kw) per layer, conv blocks then classifier; torch's init: normalize(randn)
+            self.sn_spans, uo, vo = {}, 0, 0
+            for key, (o, n, shape) in self.d_spans.items():
+                if key.endswith(".weight"):
+                    rows, cols = shape[0], n // shape[0]
+                    self.sn_spans[key[:-len("weight")]] = (uo, rows, vo, cols)
+                    uo, vo = uo + rows, vo + cols
+            assert uo == self.lib.siggan_sn_count(h, 0) and vo == self.lib.siggan_sn_count(h, 1)
+            self.d_sn_u, self.d_sn_v = z(uo), z(vo)
+            gen = torch.Generator().manual_seed(self._seed & 0x7FFFFFFF)
+            for base, (u0, rows, v0, cols) in self.sn_spans.items():
+                self.d_sn_u[u0:u0 + rows] = torch.nn.functional.normalize(torch.randn(rows, generator=gen), dim=0, eps=1e-12).to(dev)
+                self.d_sn_v[v0:v0 + cols] = torch.nn.functional.normalize(torch.randn(cols, generator=gen), dim=0, eps=1e-12).to(dev)
         self._bind()
         self.d_chans = list(layout.D_CHAIN[image_size])
 
     def _create_context(self):
         cfg = _lib.Config(self.device.index, self.latent_dim, self.image_size, 1, self.max_batch,
-                          self.dropout, self.leaky_slope, self._seed, _lib.DTYPES[self.dtype], self.f16_grad_scale)
+                          self.dropout, self.leaky_slope, self._seed, _lib.DTYPES[self.dtype], self.f16_grad_scale,
+                          int(self.spectral_norm))
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.siggan_create(C.byref(cfg), C.byref(h)))
@@ -89,7 +108,7 @@ class Engine:
         st = _lib.Storage(*[t.data_ptr() for t in (
             self.g_params, self.g_grads, self.g_exp_avg, self.g_exp_avg_sq, self.g_adam_steps, self.g_bn_mean,
             self.g_bn_var, self.g_bn_batches, self.d_params, self.d_grads, self.d_exp_avg, self.d_exp_avg_sq,
-            self.d_adam_steps)])
+            self.d_adam_steps)] + [t.data_ptr() if t is not None else 0 for t in (self.d_sn_u, self.d_sn_v)])
         _lib.check(self.lib.siggan_bind(self._h, C.byref(st)))
         self._staged = None
 
@@ -118,6 +137,14 @@ class Engine:
         spans = self.g_spans if which == "g" else self.d_spans
         flat = getattr(self, f"{which}_{arena}")
         return {k: flat[o:o + n].view(shape) for k, (o, n, shape) in spans.items()}
+
+    def sn_views(self):
+        """state_dict key -> view for the spectral-norm buffers: '<layer>.weight_u' (Cout) and '<layer>.weight_v' (Cin*kh*kw)."""
+        out = {}
+        for base, (u0, rows, v0, cols) in self.sn_spans.items():
+            out[base + "weight_u"] = self.d_sn_u[u0:u0 + rows]
+            out[base + "weight_v"] = self.d_sn_v[v0:v0 + cols]
+        return out
 
     def bn_views(self):
         out = {}

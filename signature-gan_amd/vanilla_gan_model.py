@@ -52,9 +52,6 @@ class VanillaGAN(nn.Module):
         self.latent_dim, self.image_size, self.image_channels = latent_dim, image_size, image_channels
         self.g_lr, self.d_lr, self.beta1, self.beta2 = g_lr, d_lr, beta1, beta2
         self.label_smoothing, self.use_spectral_norm = label_smoothing, use_spectral_norm
-        if use_spectral_norm:
-            raise NotImplementedError("training with a spectral-norm Discriminator is not built (SURVEY 8f-4); the stand-alone "
-                                      "Discriminator(use_spectral_norm=True) loads and scores such checkpoints in eval mode")
         if device is None:
             device = "cuda" if torch.cuda.is_available() else "cpu"
         self._device = torch.device(device)
@@ -67,7 +64,8 @@ class VanillaGAN(nn.Module):
             # whatever seed that generator was given (torch.manual_seed, or the per-process random default)
             seed = torch.initial_seed() & ((1 << 63) - 1)
         self.engine = Engine(latent_dim=latent_dim, image_size=image_size, max_batch=max_batch,
-                             device=str(self._device), seed=seed, image_channels=image_channels)
+                             device=str(self._device), seed=seed, image_channels=image_channels,
+                             spectral_norm=use_spectral_norm)
         self.generator = Generator(latent_dim=latent_dim, output_size=image_size, output_channels=image_channels,
                                    _engine=self.engine)
         self.discriminator = Discriminator(input_size=image_size, input_channels=image_channels,

@@ -280,6 +280,55 @@ def make_spectral_norm():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_spectral_norm_steps():
+    """(xii) training with a spectral-norm Discriminator: VanillaGAN(use_spectral_norm=True).train_discriminator_step /
+    train_generator_step (vanilla_gan_model.py:180-306) on the reference itself -- metrics, gradient / moment / weight probes
+    (parameter names with weight_orig), and the weight_u / weight_v buffers after each step."""
+    from collections import OrderedDict
+    from discriminator_vanilla_gan import Discriminator
+    out = {}
+    for size, latent, B in ((64, 100, 8), (128, 128, 4)):
+        z = torch.from_numpy(I.gen_z(B, latent, SEED_Z))
+        z2 = torch.from_numpy(I.gen_z(B, latent, SEED_Z + 1))
+        real = torch.from_numpy(I.gen_real(B, size, SEED_REAL))
+        plain = OrderedDict((k, (tuple(v.shape), "param")) for k, v in Discriminator(input_size=size).state_dict().items())
+
+        def model():
+            torch.manual_seed(0)
+            m = VanillaGAN(latent_dim=latent, image_size=size, image_channels=1, use_spectral_norm=True, device="cpu")
+            gs = load_state(m.generator, SEED_STATE_G)
+            m.discriminator.load_state_dict({k: torch.from_numpy(v) for k, v in I.gen_sn_state(plain, SEED_STATE_D).items()})
+            load_adam(m.g_optimizer, m.generator, gs, SEED_ADAM_G)
+            # Adam moments of D keyed by the PLAIN names (weight_orig <-> weight), in the SN module's parameter order
+            mm, vv, step = I.gen_adam(plain, SEED_ADAM_D)
+            names = [k for k, _ in m.discriminator.named_parameters()]
+            sd = m.d_optimizer.state_dict()
+            sd["state"] = {i: {"step": torch.tensor(float(step)),
+                               "exp_avg": torch.from_numpy(mm[k.replace("weight_orig", "weight")]).clone(),
+                               "exp_avg_sq": torch.from_numpy(vv[k.replace("weight_orig", "weight")]).clone()}
+                           for i, k in enumerate(names)}
+            m.d_optimizer.load_state_dict(sd)
+            return m
+        tag = f"s{size}_b{B}"
+        m = model()
+        tap = MaskTap(m.discriminator)
+        torch.manual_seed(SEED_TORCH + 7)
+        met = m.train_discriminator_step(real, noise=z)
+        tap.close()
+        out[f"{tag}/masks"] = I.pack_masks(tap.masks)
+        record_step(f"{tag}/d", m, m.discriminator, m.d_optimizer, met, out, extra_buffers=True)
+        # the G step follows on the SAME model: with D.eval() no power iteration runs, and the un-iterated random (u, v) of a
+        # fresh state would give a sigma far from the spectral norm (saturated predictions, zero gradients)
+        met = m.train_generator_step(B, noise=z2)
+        record_step(f"{tag}/g", m, m.generator, m.g_optimizer, met, out, extra_buffers=True)
+        probes(f"{tag}/g/dbuf", {k: v.float() for k, v in m.discriminator.state_dict().items() if k.endswith(("_u", "_v"))}, out)
+    out["meta"] = np.array(json.dumps({"torch": torch.__version__, "threads": torch.get_num_threads(),
+                                       "seeds": dict(z=SEED_Z, real=SEED_REAL, torch=SEED_TORCH + 7)}))
+    path = os.path.join(HERE, "golden_sn_steps.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def make_ablation_step():
     """(xi) one iteration of AblationGANTrainer.train_epoch (ablation_vanilla_gan_signatures.py:397-467) replayed statement by
     statement on the reference's own Generator / Discriminator / BCELoss / Adam objects (that file itself cannot be
@@ -366,6 +415,9 @@ if __name__ == "__main__":
     if "--ablation" in sys.argv:
         make_ablation_step()
         sys.exit(0)
+    if "--sn-steps" in sys.argv:
+        make_spectral_norm_steps()
+        sys.exit(0)
     if "--case" in sys.argv:                      # one more fixture: --case SIZE LATENT BATCH
         k = sys.argv.index("--case")
         make(int(sys.argv[k + 1]), int(sys.argv[k + 2]), int(sys.argv[k + 3]), full_image=False)
@@ -377,4 +429,5 @@ if __name__ == "__main__":
     make(64, 100, 128, full_image=False)          # BASELINE configs[3]: conv G/D 64x64, batch 128
     make_spectral_norm()
     make_ablation_step()
+    make_spectral_norm_steps()
     checkpoint_manifests()

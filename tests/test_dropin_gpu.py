@@ -183,7 +183,7 @@ def test_generation_cli_and_loaders(tmp_path):
 @pytest.mark.parametrize("size", [64, 128])
 def test_spectral_norm_discriminator_scores_like_the_reference(size):
     """Inference with a spectral-norm checkpoint: eval-mode probabilities and features against the reference's
-    (golden_spectral_norm.npz), re-normalisation when u / v change, and the refusal to train."""
+    (golden_spectral_norm.npz), re-normalisation when u / v change, and the power iteration of a train()-mode forward."""
     import json
     import os
     from common import GOLDEN, I, O, SEED
@@ -207,6 +207,9 @@ def test_spectral_norm_discriminator_scores_like_the_reference(size):
         d.conv_blocks._modules["0"].block._modules["0"].weight_u.mul_(2.0)
     feat2 = d.forward_features(x).cpu().reshape(-1).numpy()      # ... so the features move: the weights were re-normalised
     assert np.abs(feat2 - feat).max() > 1e-2 * np.abs(feat).max()
-    d.train()
-    with pytest.raises(NotImplementedError):
-        d(x)
+    d.train()                                                  # a train()-mode forward runs torch's power iteration: u, v move
+    v_before = d.state_dict()["classifier.0.weight_v"].clone()
+    p_train = d(x)
+    assert p_train.shape == (4, 1) and not torch.equal(v_before, d.state_dict()["classifier.0.weight_v"])
+    for k in ("classifier.0.weight_v", "conv_blocks.1.block.0.weight_u"):
+        assert abs(float(d.state_dict()[k].norm()) - 1.0) < 1e-4

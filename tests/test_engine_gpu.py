@@ -403,3 +403,84 @@ def test_ablation_step_variant(size, latent, batch):
     m2 = eng.train_step(cuda(real))
     assert np.isfinite(m2["d_loss"]) and np.isfinite(m2["g_loss"])
     eng.close()
+
+
+@pytest.mark.parametrize("size,latent,batch", [(64, 100, 8), (128, 128, 4)])
+def test_spectral_norm_training(size, latent, batch):
+    """Engine(spectral_norm=True): one D step then one G step (trainer variant) against the oracle's restatement of torch's
+    spectral-norm hook and against VanillaGAN(use_spectral_norm=True) run on the reference itself -- power iteration per
+    training forward (different effective weights for the real and the fake pass), gradient through sigma, u / v buffers."""
+    import os
+    from common import GOLDEN
+    from hipcommon import cuda, load_engine_state
+    from signature_gan_amd.engine import Engine
+    from test_oracle_golden import _sn_states
+    f = np.load(os.path.join(GOLDEN, "golden_sn_steps.npz"))
+    tag = f"s{size}_b{batch}"
+    masks = [torch.from_numpy(m) for m in I.unpack_masks(f[f"{tag}/masks"], batch, d_chans(size) * 2)]
+    nb = len(masks) // 2
+    z = torch.from_numpy(I.gen_z(batch, latent, SEED["z"]))
+    z2 = torch.from_numpy(I.gen_z(batch, latent, SEED["z"] + 1))
+    real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
+    eng = load_engine_state(Engine(latent_dim=latent, image_size=size, max_batch=batch, device="cuda:0", spectral_norm=True),
+                            size, latent, warm=True)
+    g_sd, d_sd, g_opt, d_opt, sn = _sn_states(size, latent)
+    for k, v in eng.sn_views().items():
+        v.copy_(sn[k])
+    ren = lambda k: k + "_orig" if k.endswith(".weight") else k
+
+    def check(which, met, o_met, o_grads, o_sd, o_opt, step_tag, gtol):
+        for k, v in o_met.items():
+            assert_close(met[k], v, 2e-4, 2e-6, f"SN {which} metric {k} vs oracle")
+            assert_close(met[k], f[f"{step_tag}/metric/{k}"], 2e-4, 2e-6, f"SN {which} metric {k} vs golden")
+        gv, mv, wv = eng.views(which, "grads"), eng.views(which, "exp_avg"), eng.views(which, "params")
+        gscale = max(float(t.abs().max()) for t in o_grads.values())
+        for k, g in gv.items():
+            rk = ren(k) if which == "d" else k
+            scale = max(float(o_grads[k].abs().max()), 1e-3 * gscale)
+            assert float((g.cpu() - o_grads[k]).abs().max()) <= gtol * scale, (which, k, float((g.cpu() - o_grads[k]).abs().max()), scale)
+            assert_close(probe(g.cpu(), rk), f[f"{step_tag}/grad/{rk}"], 0, max(gtol, 1e-3) * scale, f"SN {which} grad {k} vs golden")
+            assert float((mv[k].cpu() - o_opt.m[k]).abs().max()) <= gtol * scale, (which, k, "exp_avg")
+            assert float((wv[k].cpu() - o_sd[k]).abs().max()) <= 2.5 * 2e-4, (which, k, "weights")
+
+    met = eng.d_step(cuda(real), cuda(z), masks)
+    o_met, o_grads = O.d_step_sn(g_sd, d_sd, sn, d_opt, real, z, masks[:nb], masks[nb:], size)
+    check("d", met, o_met, o_grads, d_sd, d_opt, f"{tag}/d", 5e-3)
+    for k, v in eng.sn_views().items():                       # two power iterations later
+        _scale_close(v.cpu().numpy(), sn[k].numpy(), f"SN buffer {k} vs oracle", 1e-4)
+        _scale_close(probe(v.cpu(), k), f[f"{tag}/d/buf/{k}"], f"SN buffer {k} vs golden", 1e-4)
+    met = eng.g_step(batch, cuda(z2))
+    o_met, o_grads = O.g_step_sn(g_sd, d_sd, sn, g_opt, z2, size)
+    # (second chained step against a free-running oracle: a borderline activation sign moves single elements by ~1e-2)
+    check("g", met, o_met, o_grads, g_sd, g_opt, f"{tag}/g", 5e-2 if batch == 4 else 2e-2)
+    for k, v in eng.sn_views().items():                       # D.eval(): untouched
+        _scale_close(probe(v.cpu(), k), f[f"{tag}/g/dbuf/{k}"], f"SN buffer {k} after the G step", 1e-5)
+    eng.close()
+
+
+def test_spectral_norm_drop_in_modules():
+    """VanillaGAN(use_spectral_norm=True): the reference's SN keys as views of the engine's storage; a train_step moves
+    weight_orig, weight_u and weight_v; eval-mode scoring leaves the buffers alone; the ablation step variant runs with it."""
+    from signature_gan_amd.vanilla_gan_model import VanillaGAN
+    m = VanillaGAN(latent_dim=100, image_size=64, device="cuda:0", max_batch=8, use_spectral_norm=True, seed=5)
+    sd = m.discriminator.state_dict()
+    assert [k for k in sd if k.startswith("conv_blocks.0")] == ["conv_blocks.0.block.0.bias", "conv_blocks.0.block.0.weight_orig",
+                                                               "conv_blocks.0.block.0.weight_u", "conv_blocks.0.block.0.weight_v"]
+    before = {k: v.clone() for k, v in sd.items()}
+    real = torch.rand(8, 1, 64, 64, device="cuda:0") * 2 - 1
+    met = m.train_step(real)
+    assert np.isfinite(met["d_loss"]) and np.isfinite(met["g_loss"])
+    after = m.discriminator.state_dict()
+    for k in ("classifier.0.weight_orig", "classifier.0.weight_v", "conv_blocks.2.block.0.weight_u"):
+        assert not torch.equal(before[k], after[k]), k
+    for k in ("classifier.0.weight_u", "classifier.0.weight_v", "conv_blocks.3.block.0.weight_u"):
+        assert abs(float(after[k].norm()) - 1.0) < 1e-4, k
+    snap = {k: v.clone() for k, v in after.items()}
+    m.discriminator.eval()
+    p = m.discriminator(real)
+    assert p.shape == (8, 1) and bool(((p > 0) & (p < 1)).all())
+    for k, v in m.discriminator.state_dict().items():
+        assert torch.equal(v, snap[k]), k
+    m.engine.set_step_variant("ablation")
+    am = m.engine.ablation_step(real)
+    assert np.isfinite(am["d_loss"]) and np.isfinite(am["g_loss"])

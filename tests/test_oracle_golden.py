@@ -146,3 +146,53 @@ def test_ablation_step(size, latent, batch):
     _check_step(f, f"{tag}/d", d_opt.names, {k: v for k, v in met.items() if k.startswith("d_")}, d_grads, d_sd, d_opt)
     bufs = [k for k in g_sd if k not in g_opt.names]
     _check_step(f, f"{tag}/g", g_opt.names, {k: v for k, v in met.items() if k.startswith("g_")}, g_grads, g_sd, g_opt, bufs)
+
+
+def _sn_states(size, latent):
+    """Oracle-side states of the spectral-norm case: weight_orig under the plain names, (u, v) in their own dict."""
+    g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=True)
+    full = I.gen_sn_state(O.d_state_specs(size), SEED["state_d"])
+    sn = {k: torch.from_numpy(v).clone() for k, v in full.items() if k.endswith(("weight_u", "weight_v"))}
+    return g_sd, d_sd, g_opt, d_opt, sn
+
+
+def _sn_check(f, tag, names_plain, met, grads, sd, opt, sn=None, loose=False):
+    """_check_step against a fixture whose parameter names carry weight_orig (and whose parameter ORDER is the SN module's:
+    bias before weight_orig) -- compared by name."""
+    ren = lambda k: k.replace(".weight", ".weight_orig") if (k.endswith(".weight") and f"{tag}/grad/{k}_orig" in f) else k
+    for k, v in met.items():
+        assert_close(v, f[f"{tag}/metric/{k}"], 1e-4, 1e-6, f"{tag} metric {k}")
+    gscale = max(float(g.abs().max()) for g in grads.values())
+    # loose: a second chained step at batch 4 -- one borderline activation sign (oracle here vs the reference run) moves
+    # single gradient elements by ~1e-2 of the scale, as in test_single_steps' bounded branch
+    ga = (5e-2 if loose else 1e-6) * gscale + 1e-9
+    for k in names_plain:
+        rk = ren(k)
+        assert_close(probe(grads[k], rk), f[f"{tag}/grad/{rk}"], 1e-3, ga, f"{tag} grad {k}")
+        assert_close(probe(opt.m[k], rk), f[f"{tag}/m/{rk}"], 1e-3, ga, f"{tag} exp_avg {k}")
+        assert_close(probe(sd[k], rk), f[f"{tag}/w/{rk}"], 1e-4, 2.5e-4, f"{tag} weight {k}")
+    if sn is not None:
+        for k, t in sn.items():
+            assert_close(probe(t, k), f[f"{tag}/buf/{k}"], 1e-4, 1e-6, f"{tag} buffer {k}")
+
+
+@pytest.mark.parametrize("size,latent,batch", [(64, 100, 8), (128, 128, 4)])
+def test_spectral_norm_steps(size, latent, batch):
+    """oracle.d_step_sn / g_step_sn (power iteration per training forward, gradient through sigma) against
+    VanillaGAN(use_spectral_norm=True) run on the reference itself (make_golden.py::make_spectral_norm_steps)."""
+    import os
+    from common import GOLDEN, d_chans
+    f = np.load(os.path.join(GOLDEN, "golden_sn_steps.npz"))
+    tag = f"s{size}_b{batch}"
+    masks = [torch.from_numpy(m) for m in I.unpack_masks(f[f"{tag}/masks"], batch, d_chans(size) * 2)]
+    nb = len(masks) // 2
+    z = torch.from_numpy(I.gen_z(batch, latent, SEED["z"]))
+    z2 = torch.from_numpy(I.gen_z(batch, latent, SEED["z"] + 1))
+    real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
+    g_sd, d_sd, g_opt, d_opt, sn = _sn_states(size, latent)
+    met, grads = O.d_step_sn(g_sd, d_sd, sn, d_opt, real, z, masks[:nb], masks[nb:], size)
+    _sn_check(f, f"{tag}/d", d_opt.names, met, grads, d_sd, d_opt, sn)
+    met, grads = O.g_step_sn(g_sd, d_sd, sn, g_opt, z2, size)              # on the state the D step left (as the fixture)
+    _sn_check(f, f"{tag}/g", g_opt.names, met, grads, g_sd, g_opt, loose=(batch == 4))
+    for k, t in sn.items():                                        # D.eval(): the buffers did not move
+        assert_close(probe(t, k), f[f"{tag}/g/dbuf/{k}"], 1e-6, 1e-7, f"G step leaves {k} alone")
