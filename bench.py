@@ -195,13 +195,14 @@ def main():
         top = max(recs, key=lambda r: r["ms"])
         ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
         gbps = top["bytes"] / (top["ms"] * 1e-3) / 1e9
-        traffic, traffic_src = None, None      # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
+        traffic, traffic_src, step_bytes = None, None, None   # HBM bytes from the committed PMC passes (separate rocprofv3 runs)
         tag = "" if (dtype, size, batch) == ("f32", 64, 64) else f"_{dtype}_s{size}_b{batch}"
         tfile = os.path.join("profiles", f"r02_pmc_traffic{tag}.json")
         try:
             with open(os.path.join(ROOT, tfile)) as f:
                 tj = json.load(f)
             traffic = tj["per_launch_bytes"][top["name"]]["total"]
+            step_bytes = tj.get("per_step_bytes_all_library_kernels")
             traffic_src = {"file": tfile, "commit": tj.get("commit"), "note": "separate rocprofv3 --pmc passes of this workload, "
                            "FETCH_SIZE doubled per MI355X_MICROARCH.md; not measured in this run"}
         except (OSError, KeyError, ValueError):
@@ -217,6 +218,10 @@ def main():
             "gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 4),
             "hbm": {"algorithmic_mb_per_launch": round(top["bytes"] / top["launches"] / 1e6, 3), "achieved": round(gbps, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)},
+            # whole step: HBM bytes of ALL kernels of one step (same PMC passes) over this run's step time
+            "hbm_whole_step": None if not step_bytes else {
+                "mb_per_step": round(step_bytes / 1e6, 1), "achieved": round(step_bytes / (dt / args.steps) / 1e9, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)},
             "mfma_family": {"ms_per_step": round(fam_ms / args.steps, 4),
                             "achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 3),
                             "kernels": {r["name"]: {"launches_per_step": r["launches"] / args.steps,
