@@ -40,6 +40,17 @@ class Hyper(C.Structure):
                 ("label_smoothing", C.c_float), ("clip_max_norm", C.c_float), ("grad_scale", C.c_float)]
 
 
+class MlpConfig(C.Structure):       # include/siggan_mlp.h
+    _fields_ = [("device", C.c_int32), ("latent_dim", C.c_int32), ("image_size", C.c_int32), ("n_hidden", C.c_int32),
+                ("hidden", C.c_int32 * 4), ("max_batch", C.c_int32), ("leaky_slope", C.c_float), ("seed", C.c_uint64)]
+
+
+class MlpStorage(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "g_params", "g_grads", "g_exp_avg", "g_exp_avg_sq", "g_adam_steps", "g_bn_running_mean",
+        "g_bn_running_var", "g_bn_batches", "d_params", "d_grads", "d_exp_avg", "d_exp_avg_sq", "d_adam_steps")]
+
+
 _P, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
 _SIGNATURES = {
     "siggan_abi_version": (C.c_int, []),
@@ -85,6 +96,19 @@ _SIGNATURES = {
     "siggan_prof_read": (C.c_int, [_P, _I32, C.c_char_p, _I32, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
     "siggan_debug_tensor": (C.c_int, [_P, C.c_char_p, _I32, _P, _I64, _P]),
+    # fully-connected extension (include/siggan_mlp.h; build-defined, parity unpinned)
+    "mlpgan_create": (C.c_int, [C.POINTER(MlpConfig), C.POINTER(_P)]),
+    "mlpgan_destroy": (C.c_int, [_P]),
+    "mlpgan_param_count": (_I64, [_P, C.c_int]),
+    "mlpgan_param_tensors": (_I32, [_P, C.c_int]),
+    "mlpgan_bn_count": (_I64, [_P]),
+    "mlpgan_bind": (C.c_int, [_P, C.POINTER(MlpStorage)]),
+    "mlpgan_seed": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
+    "mlpgan_g_forward": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),
+    "mlpgan_d_forward": (C.c_int, [_P, _P, _I32, _P, _P]),
+    "mlpgan_d_step": (C.c_int, [_P, _P, _I32, _P, C.POINTER(Hyper), _P, _P]),
+    "mlpgan_g_step": (C.c_int, [_P, _I32, _P, C.POINTER(Hyper), _P, _P]),
+    "mlpgan_op_gemm": (C.c_int, [_I32, _I32, _P, _P, _P, _I32, _I32, _I32, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

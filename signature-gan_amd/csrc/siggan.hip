@@ -27,6 +27,14 @@ static int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+// (mlp.hip reports through the same thread-local message)
+int siggan_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
         hipError_t e_ = (x);                                                                        \

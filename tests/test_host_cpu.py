@@ -18,12 +18,12 @@ from signature_gan_amd import _lib, layout
 
 
 def test_library_exports_every_declared_symbol():
-    header = open(os.path.join(ROOT, "include", "siggan.h")).read()
-    declared = set(re.findall(r"\b(siggan_[a-z0-9_]+)\s*\(", header))
-    declared -= {"siggan_ctx", "siggan_config", "siggan_storage", "siggan_hyper"}
+    header = open(os.path.join(ROOT, "include", "siggan.h")).read() + open(os.path.join(ROOT, "include", "siggan_mlp.h")).read()
+    declared = set(re.findall(r"\b((?:siggan|mlpgan)_[a-z0-9_]+)\s*\(", header))
+    declared -= {"siggan_ctx", "siggan_config", "siggan_storage", "siggan_hyper", "mlpgan_ctx", "mlpgan_config", "mlpgan_storage"}
     lib = _lib.load()
     for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in include/siggan.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
     assert lib.siggan_abi_version() == _lib.ABI_VERSION
 
@@ -188,3 +188,54 @@ def test_spectral_norm_discriminator_keys_match_the_reference():
         assert sum(p.numel() for p in d.parameters()) == sum(p.numel() for p in Discriminator(input_size=size).parameters())
     with pytest.raises(RuntimeError):                 # spectral-norm training is built; like every model it needs the MI355X
         VanillaGAN(use_spectral_norm=True, device="cpu")
+
+
+def test_mlp_oracle_matches_an_nn_module_restatement():
+    """The fully-connected extension has no reference model (parity unpinned): its oracle is at least checked against an
+    independent nn.Module / autograd / torch.optim.Adam spelling of the same definition."""
+    import torch.nn as nn
+    from oracle import mlp_oracle as M
+    from oracle.siggan_oracle import AdamState
+    size, hidden, B = 28, (64, 96), 6
+    gen = torch.Generator().manual_seed(0)
+    G = nn.Sequential()
+    k = 100
+    g_sd = {}
+    for i, h in enumerate(hidden):
+        lin, bn = nn.Linear(k, h), nn.BatchNorm1d(h)
+        G.append(lin); G.append(bn); G.append(nn.ReLU())
+        g_sd.update({f"net.{i}.linear.weight": lin.weight, f"net.{i}.linear.bias": lin.bias, f"net.{i}.bn.weight": bn.weight,
+                     f"net.{i}.bn.bias": bn.bias, f"net.{i}.bn.running_mean": bn.running_mean, f"net.{i}.bn.running_var": bn.running_var,
+                     f"net.{i}.bn.num_batches_tracked": bn.num_batches_tracked})
+        k = h
+    out = nn.Linear(k, size * size); G.append(out); G.append(nn.Tanh())
+    g_sd.update({"out.weight": out.weight, "out.bias": out.bias})
+    D = nn.Sequential(nn.Flatten())
+    d_sd, k = {}, size * size
+    for j, h in enumerate(reversed(hidden)):
+        lin = nn.Linear(k, h); D.append(lin); D.append(nn.LeakyReLU(0.2))
+        d_sd.update({f"net.{j}.weight": lin.weight, f"net.{j}.bias": lin.bias}); k = h
+    lin = nn.Linear(k, 1); D.append(lin); D.append(nn.Sigmoid()); d_sd.update({"out.weight": lin.weight, "out.bias": lin.bias})
+    o_g = {k_: v.detach().clone() for k_, v in g_sd.items()}
+    o_d = {k_: v.detach().clone() for k_, v in d_sd.items()}
+    g_names = [k_ for k_ in o_g if "running" not in k_ and "num_batches" not in k_]
+    g_opt, d_opt = AdamState(g_names, o_g), AdamState(list(o_d), o_d)
+    z, z2 = torch.randn(B, 100, generator=gen), torch.randn(B, 100, generator=gen)
+    real = torch.rand(B, 1, size, size, generator=gen) * 2 - 1
+    optD, optG, crit = torch.optim.Adam(D.parameters(), 2e-4, betas=(0.5, 0.999)), torch.optim.Adam(G.parameters(), 2e-4, betas=(0.5, 0.999)), nn.BCELoss()
+    D.train(); G.eval(); optD.zero_grad()
+    with torch.no_grad():
+        fake = G(z).view(-1, 1, size, size)
+    loss = crit(D(real), torch.full((B, 1), 0.9)) + crit(D(fake), torch.zeros(B, 1)); loss.backward(); optD.step()
+    met, _ = M.d_step(o_g, o_d, d_opt, real, z, hidden, size)
+    assert abs(met["d_loss"] - float(loss)) <= 1e-5
+    for k_, v in d_sd.items():
+        assert float((v.detach() - o_d[k_]).abs().max()) <= 1e-6, k_
+    G.train(); optG.zero_grad()
+    gl = crit(D(G(z2).view(-1, 1, size, size)), torch.ones(B, 1)); gl.backward(); optG.step()
+    met, _ = M.g_step(o_g, o_d, g_opt, z2, hidden, size)
+    assert abs(met["g_loss"] - float(gl)) <= 1e-5
+    for k_, v in g_sd.items():
+        # (a Linear bias in front of BatchNorm has a zero true gradient: Adam moves it by up to lr on rounding noise)
+        tol = 2.5 * 2e-4 if k_.endswith("linear.bias") else 1e-5
+        assert float((v.detach().float() - o_g[k_].float()).abs().max()) <= tol, k_
