@@ -81,6 +81,66 @@ def cpu_baseline(threads, size, latent, batch, budget_s=12.0):
     return batch * n / dt, n
 
 
+def bench_mlp(args):
+    """BASELINE.json configs[0] as worded (fully-connected G/D, 28x28, batch 32): a BUILD-DEFINED extension with no reference
+    model -- parity unpinned (include/siggan_mlp.h).  Same timing protocol; the CPU leg times the extension's own oracle."""
+    import torch
+    import signature_gan_amd  # noqa: F401
+    from signature_gan_amd.mlp_gan import MLPGAN
+    size, batch, hidden = args.size, args.batch, (256, 512)
+    torch.cuda.set_device(0)
+    m = MLPGAN(latent_dim=100, image_size=size, hidden=hidden, max_batch=batch, device="cuda:0", seed=2)
+    real = (torch.rand(batch, 1, size, size, generator=torch.Generator().manual_seed(1)) * 2 - 1).cuda()
+    for _ in range(args.warmup):
+        m.train_step(real, sync=False)
+    blocks = []
+    for _ in range(max(1, args.blocks)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            m.train_step(real, sync=False)
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+    dt = statistics.median(blocks)
+    met = m.metrics.cpu()
+    assert torch.isfinite(met).all()
+    dims = [100, *hidden, size * size]
+    fwd = sum(2 * a * b for a, b in zip(dims[:-1], dims[1:]))            # G forward = D forward (mirror) FLOP per image, + the 1-wide head
+    flop_img = 8 * (fwd - 2 * 100 * hidden[0] + 2 * hidden[0]) + 4 * fwd   # 8 x D_fwd + 4 x G_fwd, as for the conv model
+    cpu = None
+    if not args.no_cpu:
+        from oracle import mlp_oracle as M
+        from oracle.siggan_oracle import AdamState
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        g_sd = {k: v.cpu().clone() for k, v in m.views("g").items()}
+        g_sd.update({k: v.cpu().clone() for k, v in m.bn_views().items()})
+        d_sd = {k: v.cpu().clone() for k, v in m.views("d").items()}
+        g_opt, d_opt = AdamState(list(m.g_spans), g_sd), AdamState(list(m.d_spans), d_sd)
+        rc, n, t0 = real.cpu(), 0, time.perf_counter()
+        while time.perf_counter() - t0 < 8.0:
+            M.d_step(g_sd, d_sd, d_opt, rc, torch.randn(batch, 100), hidden, size)
+            M.g_step(g_sd, d_sd, g_opt, torch.randn(batch, 100), hidden, size)
+            n += 1
+        cpu = {"value": round(batch * n / (time.perf_counter() - t0), 1), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{n} G+D steps of the same workload by oracle/mlp_oracle.py (torch CPU; the extension's own restatement: parity unpinned)"}
+    cus, khz, _ = __import__("signature_gan_amd.engine", fromlist=["Engine"]).Engine.device_info(0)
+    peak = cus * khz * 1e3 * FLOP_PER_CLK_PER_CU["f32"] / 1e12
+    imgs = batch * args.steps
+    print(json.dumps({
+        "metric": f"signature images/sec (MLP G+D train step, bs{batch} {size}x{size} z=100)", "value": round(imgs / dt, 1), "unit": "images/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[0] as worded: fully-connected G 100-256-512-{size * size} / mirror D, {size}x{size}x1, batch {batch}, fp32 -- "
+                               "BUILD-DEFINED extension, the reference has no such model: PARITY UNPINNED", "global_batch": batch, "parallelism": "dp1"},
+        "timing": {"blocks": len(blocks), "stat": "median", "ms_per_step_p10": round(1e3 * pct(blocks, 0.1) / args.steps, 4),
+                   "ms_per_step_p90": round(1e3 * pct(blocks, 0.9) / args.steps, 4)},
+        "achieved_tflops_whole_step": round(imgs / dt * flop_img / 1e12, 4),
+        "frac_of_mfma_peak_whole_step": round(imgs / dt * flop_img / 1e12 / peak, 6),
+        "roofline": None, "note": "launch-bound: ~0.4 GFLOP per step spread over ~45 launches; no kernel of this path is near any roofline",
+        "final_metrics": {"d_loss": round(float(met[0]), 4), "g_loss": round(float(met[8]), 4)}, "cpu_baseline": cpu}), flush=True)
+    m.close()
+
+
 def pct(xs, q):
     xs = sorted(xs)
     return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
@@ -93,7 +153,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--blocks", type=int, default=10, help="timed blocks of --steps steps (median / p10 / p90 over them)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
-    ap.add_argument("--size", type=int, default=64, choices=[64, 128])
+    ap.add_argument("--model", default="conv", choices=["conv", "mlp"],
+                    help="conv: the reference's G/D (default, the headline). mlp: the fully-connected extension (configs[0], parity unpinned)")
+    ap.add_argument("--size", type=int, default=None, help="64 | 128 (conv); any (mlp, default 28)")
     ap.add_argument("--latent", type=int, default=None)
     ap.add_argument("--batch", type=int, default=64, help="batch PER GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -107,6 +169,12 @@ def main():
                     help="N > 1: reduce the gradient buckets with torch.distributed between the step halves instead of the "
                          "library's own communicator (fallback / comparison)")
     args = ap.parse_args()
+    if args.model == "mlp":
+        args.size = args.size or 28
+        return bench_mlp(args)
+    args.size = args.size or 64
+    if args.size not in (64, 128):
+        ap.error("--size must be 64 or 128 for the conv model")
     size, batch, dtype = args.size, args.batch, args.dtype
     latent = args.latent if args.latent is not None else (100 if size == 64 else 128)
 
