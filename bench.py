@@ -181,7 +181,7 @@ def main():
     import torch
     import torch.distributed as dist
     import signature_gan_amd  # noqa: F401
-    from signature_gan_amd.dp import DataParallelStep, env_rank
+    from signature_gan_amd.dp import DataParallelStep, env_rank, init_library_comm
     from signature_gan_amd.engine import Engine
 
     rank, world, local = env_rank()
@@ -209,6 +209,27 @@ def main():
     if args.serialize:
         eng.set_mode(graph=False, overlap=False)
     transport = "host" if (args.host_allreduce or not grouped) else "lib"
+    comm_note = None
+    if transport == "lib":
+        # the library's own RCCL communicator; if ANY rank fails to create it, every rank falls back to reducing the two
+        # gradient arenas with torch.distributed between the step halves (same arithmetic), and the line says so
+        ok = 1
+        try:
+            if os.environ.get("SIGGAN_BENCH_FORCE_COMM_FAILURE"):  # rehearsal hook for the fallback below
+                raise RuntimeError("forced by SIGGAN_BENCH_FORCE_COMM_FAILURE")
+            init_library_comm(eng)
+        except Exception as exc:                                 # noqa: BLE001 -- reported in the JSON line
+            ok, comm_note = 0, f"{type(exc).__name__}: {exc}"
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            if eng.comm_world > 0:
+                eng.comm_destroy()
+            transport, comm_note = "host", comm_note or "another rank failed to create the library communicator"
+            print(f"[bench] rank {rank}: library RCCL communicator unavailable ({comm_note}); using torch.distributed",
+                  file=sys.stderr, flush=True)
     dp = DataParallelStep(eng, transport=transport)
     dp.sync_initial_state()
     gen = torch.Generator(device="cpu").manual_seed(1 + rank)
@@ -326,7 +347,8 @@ def main():
             "config": {"workload": f"{cfg_name}: reference conv G/D {size}x{size}x1, z={latent}, batch {batch} per GPU, {dtype}, n_critic=1",
                        "global_batch": batch * world, "parallelism": f"dp{world}",
                        "gradient_allreduce": None if world == 1 and not grouped else
-                       ("library RCCL (siggan_comm_init)" if transport == "lib" else "torch.distributed between the step halves")},
+                       ("library RCCL (siggan_comm_init)" if transport == "lib" else "torch.distributed between the step halves"
+                        + (f" (fallback: {comm_note})" if comm_note else ""))},
             "timing": {"blocks": len(block_s), "steps_per_block": args.steps, "stat": "median",
                        "ms_per_step_p10": round(1e3 * pct(block_s, 0.1) / args.steps, 4),
                        "ms_per_step_p90": round(1e3 * pct(block_s, 0.9) / args.steps, 4),
