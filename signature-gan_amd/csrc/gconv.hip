@@ -31,7 +31,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WM, int WN, int BK = 32>
+template <int BM, int BN, int WM, int WN, int BK = 32, int DEEP = 0>
 __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int PA = BM / 32, PB = BN / 32;
@@ -103,32 +103,33 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
             a_step[p] = ok ? BK : 0;
         }
     };
-    f32x4 ra[PA][KC], rb[PB][KC];
-    auto load_tile = [&]() __attribute__((always_inline)) {
+    constexpr int NSET = DEEP ? 2 : 1;      // register sets: tile t waits in set t % NSET
+    f32x4 ra[NSET][PA][KC], rb[NSET][PB][KC];
+    auto load_tile = [&](int set = 0) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
 #pragma unroll
-            for (int q = 0; q < KC; ++q) ra[p][q] = *reinterpret_cast<const f32x4*>(a_cur[p] + 32 * q);   // (zero page: 256 B)
+            for (int q = 0; q < KC; ++q) ra[set][p][q] = *reinterpret_cast<const f32x4*>(a_cur[p] + 32 * q);   // (zero page: 256 B)
             a_cur[p] += a_step[p];
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p)
 #pragma unroll
-            for (int q = 0; q < KC; ++q) rb[p][q] = *reinterpret_cast<const f32x4*>(wcur + (size_t)(32 * p) * Ktot + 32 * q);
+            for (int q = 0; q < KC; ++q) rb[set][p][q] = *reinterpret_cast<const f32x4*>(wcur + (size_t)(32 * p) * Ktot + 32 * q);
         wcur += BK;
         if (++l_cc == (1 << lgcpt)) { l_cc = 0; ++l_tap; set_tap(); }
     };
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    auto store_tile = [&](int buf, int set = 0) __attribute__((always_inline)) {
         float* dA = sA + buf * LD * BM + rloc * LD + kc * 4;
         float* dB = sB + buf * LD * BN + rloc * LD + kc * 4;
 #pragma unroll
         for (int p = 0; p < PA; ++p)
 #pragma unroll
-            for (int q = 0; q < KC; ++q) *reinterpret_cast<f32x4*>(dA + 32 * p * LD + 32 * q) = ra[p][q];
+            for (int q = 0; q < KC; ++q) *reinterpret_cast<f32x4*>(dA + 32 * p * LD + 32 * q) = ra[set][p][q];
 #pragma unroll
         for (int p = 0; p < PB; ++p)
 #pragma unroll
-            for (int q = 0; q < KC; ++q) *reinterpret_cast<f32x4*>(dB + 32 * p * LD + 32 * q) = rb[p][q];
+            for (int q = 0; q < KC; ++q) *reinterpret_cast<f32x4*>(dB + 32 * p * LD + 32 * q) = rb[set][p][q];
     };
 
     f32x16 acc[TM][TN];
@@ -143,6 +144,59 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     // behind the first MFMAs of a tile and immediately re-loaded with the tile after that, so every
     // global load has a full K-tile of MFMA time to land (hipcc drains vmcnt to 0 at the LDS write
     // whatever is newer in flight, so the write sits where nothing newer is).
+    if (DEEP && nk >= 5) {
+        // Two tiles ahead: the loads of tile t are issued while tile t-3 is multiplied and are needed (LDS write) while tile
+        // t-1 is -- two K-tiles of time to land instead of one.  A K-tile of this kernel lasts about as long as a load
+        // that misses L2 takes, so with one tile of slack every tile waited for its slowest load.  Two register sets; the
+        // loop is unrolled by two so that set and buffer indices are compile-time, and the steady part issues its loads
+        // unconditionally: only then can hipcc count the loads in flight and wait for the OLDER set alone (vmcnt(4));
+        // one conditional load anywhere on the path and it drains the queue (vmcnt(0)) at every LDS write.
+        auto tile = [&](const int h, const int kt, const bool st, const bool ld) __attribute__((always_inline)) {
+            const float* pA = sA + h * LD * BM + (wm * (32 * TM) + li) * LD + 4 * lh;
+            const float* pB = sB + h * LD * BN + (wn * (32 * TN) + li) * LD + 4 * lh;
+            f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(pA + 32 * i * LD);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(pB + 32 * j * LD);
+#pragma unroll
+            for (int c = 0; c < BK / 8; ++c) {
+                const int cur = c & 1, nxt = cur ^ 1;
+                if (c + 1 < BK / 8) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const f32x4*>(pA + 32 * i * LD + 8 * (c + 1));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const f32x4*>(pB + 32 * j * LD + 8 * (c + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
+                if (c == 0 && st) store_tile(h ^ 1, h ^ 1);     // tile kt+1 (set (kt+1)&1): loaded two tiles ago
+                if (c == 1 && ld) load_tile(h ^ 1);             // tile kt+3 into the set just written out
+            }
+            __syncthreads();
+        };
+        set_tap();
+        load_tile(0);
+        load_tile(1);
+        store_tile(0, 0);
+        load_tile(0);
+        __syncthreads();
+        int kt = 0;
+        for (; kt + 4 < nk; kt += 2) {           // both halves have a tile kt+3 to load
+            tile(0, kt, true, true);
+            tile(1, kt + 1, true, true);
+        }
+        for (; kt < nk; kt += 2) {               // the last three or four tiles
+            tile(0, kt, kt + 1 < nk, kt + 3 < nk);
+            if (kt + 1 < nk) tile(1, kt + 1, kt + 2 < nk, kt + 4 < nk);
+        }
+    } else {
     if (nk > 0) {
         set_tap();
         load_tile();
@@ -185,6 +239,7 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
 #endif
         }
         __syncthreads();
+    }
     }
 
     // ---- epilogue ----------------------------------------------------------------------
@@ -445,7 +500,7 @@ static double wgrad_bytes(const WgradArgs& a) {
     return es * ((double)a.K * a.Cs + 4.0 * a.K * a.Cl) + 4.0 * 16.0 * a.Cs * a.Cl;
 }
 
-template <int BM, int BN, int WM, int WN, int BKT = 32>
+template <int BM, int BN, int WM, int WN, int BKT = 32, int DEEP = 0>
 static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
     const int ncls = a.form == 0 ? 1 : 4;
@@ -456,9 +511,9 @@ static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     if (a.dt != DT_F32) {
         launch_gconv16(id, a, grid, st, e0, e1);
     } else if (g_prof) {
-        hipExtLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT>), grid, dim3(256), 0, st, e0, e1, 0, a);
+        hipExtLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT, DEEP>), grid, dim3(256), 0, st, e0, e1, 0, a);
     } else {
-        hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT, DEEP>), grid, dim3(256), 0, st, a);
     }
     if (nsplit > 1) {
         const int64_t total4 = (int64_t)a.B * a.Ho * a.Wo * a.Co / 4;
@@ -491,9 +546,9 @@ void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
     if (a.Co >= 64) {
         // 128x128 (four accumulators per wave, 82 % MFMA-busy) only when it still yields two workgroups per CU; the
         // 128x64 middle size measured below 64x64 on every shape of the step (86 vs 93 TFLOP/s) and is not built
-        if (a.Co >= 128 && blocks(128, 128) >= 512) return launch_cfg<128, 128, 2, 2>(a, st, 0, 1);
+        if (a.Co >= 128 && blocks(128, 128) >= 512) return launch_cfg<128, 128, 2, 2, 32, 1>(a, st, 0, 1);
         const int ns = splits(blocks(64, 64));
-        return launch_cfg<64, 64, 2, 2>(a, st, 2, ns);
+        return launch_cfg<64, 64, 2, 2, 32, 1>(a, st, 2, ns);
     }
     if (a.dt == DT_F32 && a.form == 1 && a.Co == 32 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU) && (a.Ci == 32 || a.Ci == 64) &&
         a.M / 128 >= (a.Ci == 32 ? 384 : 768) && a.M % 128 == 0 &&
@@ -507,7 +562,7 @@ void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         return;
     }
     const int ns = splits(blocks(128, 32));
-    return launch_cfg<128, 32, 4, 1>(a, st, 3, ns);   // Co == 32
+    return launch_cfg<128, 32, 4, 1, 32, 1>(a, st, 3, ns);   // Co == 32
 }
 
 // ------------------------------------------------------------------------------------------
@@ -541,15 +596,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
     const int jj = j0 + cb * 4, tap = jj >> a.lgCl, lch = jj & (Cl - 1);
     const int kh = tap >> 2, kw = tap & 3;
 
-    f32x4 ra[PA], rb[PB];
+    f32x4 ra[2][PA], rb[2][PB];          // two register sets: tile t waits in set t & 1 (second set: the deep path only)
     // (macros, not lambdas: hipcc left the staged float4 arrays in scratch when these were lambdas)
-#define WG_LOAD_TILE(KT)                                                                              \
+#define WG_LOAD_TILE(KT, SET)                                                                         \
     {                                                                                                 \
         const int kbase = kbeg + (KT) * BK;                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                              \
             const int pix = kbase + ka + RA * p;                                                      \
             const float* src = pix < kend ? a_S + ((size_t)pix * a.Cs + i0 + ca * 4) : a.zeros;       \
-            ra[p] = *reinterpret_cast<const f32x4*>(src);                                            \
+            ra[SET][p] = *reinterpret_cast<const f32x4*>(src);                                       \
         }                                                                                             \
         _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                              \
             const int pix = kbase + kb + RB * p;                                                      \
@@ -557,15 +612,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
             const int ih = 2 * ((pix >> a.lgWs) & (Hs - 1)) - 1 + kh, iw = 2 * (pix & (Ws - 1)) - 1 + kw; \
             const bool ok = pix < kend && (unsigned)ih < (unsigned)Hl && (unsigned)iw < (unsigned)Wl; \
             const float* src = ok ? a_L + ((((size_t)n * Hl + ih) * Wl + iw) * Cl + lch) : a.zeros;   \
-            rb[p] = *reinterpret_cast<const f32x4*>(src);                                            \
+            rb[SET][p] = *reinterpret_cast<const f32x4*>(src);                                       \
         }                                                                                             \
     }
-#define WG_STORE_TILE(BUF)                                                                            \
+#define WG_STORE_TILE(BUF, SET)                                                                       \
     {                                                                                                 \
         _Pragma("unroll") for (int p = 0; p < PA; ++p)                                                \
-            *reinterpret_cast<f32x4*>(sA + (BUF) * BK * LDA + (ka + RA * p) * LDA + ca * 4) = ra[p]; \
+            *reinterpret_cast<f32x4*>(sA + (BUF) * BK * LDA + (ka + RA * p) * LDA + ca * 4) = ra[SET][p]; \
         _Pragma("unroll") for (int p = 0; p < PB; ++p)                                                \
-            *reinterpret_cast<f32x4*>(sB + (BUF) * BK * LDB + (kb + RB * p) * LDB + cb * 4) = rb[p]; \
+            *reinterpret_cast<f32x4*>(sB + (BUF) * BK * LDB + (kb + RB * p) * LDB + cb * 4) = rb[SET][p]; \
     }
 
     f32x16 acc[TM][TN];
@@ -576,52 +631,69 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nk > 0) {
-        WG_LOAD_TILE(0)
-        WG_STORE_TILE(0)
-        if (nk > 1) WG_LOAD_TILE(1)
-    }
-    __syncthreads();
     // column sums of S (the bias gradient when S is d(pre-activation)) ride along in the first column tile: thread t
     // owns column t % BM and the k rows [kq * KQ, kq * KQ + KQ) of every K-tile, the slices are added at the end
     constexpr int NQ = 256 / BM, KQ = BK / NQ;
     const bool bias_blk = a.db != nullptr && j0 == 0;
     const int bcol = tid % BM, kq = tid / BM;
     float bsum = 0.f;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (bias_blk) {
-            const float* col = sA + buf * BK * LDA + kq * KQ * LDA + bcol;
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) bsum += col[k * LDA];
+    // one K-tile out of LDS buffer BUF; ST / LD: an LDS write / a global load of a later tile rides along (see below)
+#define WG_TILE(BUF, ST, LD)                                                                          \
+    {                                                                                                 \
+        if (bias_blk) {                                                                               \
+            const float* col = sA + (BUF) * BK * LDA + kq * KQ * LDA + bcol;                          \
+            _Pragma("unroll") for (int k = 0; k < KQ; ++k) bsum += col[k * LDA];                      \
+        }                                                                                             \
+        const float* pA = sA + (BUF) * BK * LDA + lh * LDA + wm * (32 * TM) + li;                     \
+        const float* pB = sB + (BUF) * BK * LDB + lh * LDB + wn * (32 * TN) + li;                     \
+        float fa[2][TM], fb[2][TN];                                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = pA[32 * i];                         \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = pB[32 * j];                         \
+        _Pragma("unroll") for (int s = 0; s < BK / 2; ++s) {                                          \
+            const int cur = s & 1, nxt = cur ^ 1;                                                     \
+            if (s + 1 < BK / 2) {                                                                     \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[nxt][i] = pA[(2 * s + 2) * LDA + 32 * i]; \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[nxt][j] = pB[(2 * s + 2) * LDB + 32 * j]; \
+            }                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0); \
+            if (s == 0) { ST }                                                                        \
+            if (s == 1) { LD }                                                                        \
+        }                                                                                             \
+        __syncthreads();                                                                              \
+    }
+    if (nk >= 5) {
+        // two tiles ahead (see k_gconv): tile t is loaded while tile t-3 is multiplied and written to LDS while tile t-1 is;
+        // the steady loop issues its loads unconditionally so that the LDS write waits for the older register set only
+        WG_LOAD_TILE(0, 0)
+        WG_LOAD_TILE(1, 1)
+        WG_STORE_TILE(0, 0)
+        WG_LOAD_TILE(2, 0)
+        __syncthreads();
+        int kt = 0;
+        for (; kt + 4 < nk; kt += 2) {
+            WG_TILE(0, WG_STORE_TILE(1, 1), WG_LOAD_TILE(kt + 3, 1))
+            WG_TILE(1, WG_STORE_TILE(0, 0), WG_LOAD_TILE(kt + 4, 0))
         }
-        const float* pA = sA + buf * BK * LDA + lh * LDA + wm * (32 * TM) + li;
-        const float* pB = sB + buf * BK * LDB + lh * LDB + wn * (32 * TN) + li;
-        float fa[2][TM], fb[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[0][i] = pA[32 * i];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = pB[32 * j];
-#pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s + 1 < BK / 2) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[nxt][i] = pA[(2 * s + 2) * LDA + 32 * i];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[nxt][j] = pB[(2 * s + 2) * LDB + 32 * j];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-            if (s == 0 && kt + 1 < nk) WG_STORE_TILE(buf ^ 1)
-            if (s == 1 && kt + 2 < nk) WG_LOAD_TILE(kt + 2)
+        for (; kt < nk; kt += 2) {
+            WG_TILE(0, if (kt + 1 < nk) WG_STORE_TILE(1, 1), if (kt + 3 < nk) WG_LOAD_TILE(kt + 3, 1))
+            if (kt + 1 < nk) WG_TILE(1, if (kt + 2 < nk) WG_STORE_TILE(0, 0), if (kt + 4 < nk) WG_LOAD_TILE(kt + 4, 0))
+        }
+    } else {
+        if (nk > 0) {
+            WG_LOAD_TILE(0, 0)
+            WG_STORE_TILE(0, 0)
+            if (nk > 1) WG_LOAD_TILE(1, 0)
         }
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt & 1) WG_TILE(1, if (kt + 1 < nk) WG_STORE_TILE(0, 0), if (kt + 2 < nk) WG_LOAD_TILE(kt + 2, 0))
+            else WG_TILE(0, if (kt + 1 < nk) WG_STORE_TILE(1, 0), if (kt + 2 < nk) WG_LOAD_TILE(kt + 2, 0))
+        }
     }
+#undef WG_TILE
 
 #undef WG_LOAD_TILE
 #undef WG_STORE_TILE
