@@ -597,22 +597,38 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
     const int kh = tap >> 2, kw = tap & 3;
 
     f32x4 ra[2][PA], rb[2][PB];          // two register sets: tile t waits in set t & 1 (second set: the deep path only)
+    // Tiles are loaded strictly in K order, so the loader keeps running state instead of deriving addresses from the tile
+    // index: the S pointer advances by a constant, and the gathered L address is a handful of shifts (every extent is a power
+    // of two) off the running pixel index.  The first version recomputed both from scratch with 64-bit multiplies: 1100 cycles
+    // of VALU work per K-tile, which the matrix pipe does not hide (a wave's VALU instructions queue behind its own MFMAs).
+    // (offsets from the kernel-argument pointers, not running pointers: a loop-carried pointer loses its address space and
+    // hipcc falls back to flat loads, whose counter semantics also cost the exact vmcnt waits of the deep path)
+    size_t a_off[PA];
+    int a_pix[PA], b_pix[PB];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) { a_pix[p] = kbeg + ka + RA * p; a_off[p] = (size_t)a_pix[p] * a.Cs + i0 + ca * 4; }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) b_pix[p] = kbeg + kb + RB * p;
+    const int a_adv = BK * a.Cs;
+    const int lgWl = a.lgWs + 1;
     // (macros, not lambdas: hipcc left the staged float4 arrays in scratch when these were lambdas)
 #define WG_LOAD_TILE(KT, SET)                                                                         \
     {                                                                                                 \
-        const int kbase = kbeg + (KT) * BK;                                                           \
         _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                              \
-            const int pix = kbase + ka + RA * p;                                                      \
-            const float* src = pix < kend ? a_S + ((size_t)pix * a.Cs + i0 + ca * 4) : a.zeros;       \
+            const float* src = a_pix[p] < kend ? a_S + a_off[p] : a.zeros;                            \
             ra[SET][p] = *reinterpret_cast<const f32x4*>(src);                                       \
+            a_off[p] += a_adv; a_pix[p] += BK;                                                        \
         }                                                                                             \
         _Pragma("unroll") for (int p = 0; p < PB; ++p) {                                              \
-            const int pix = kbase + kb + RB * p;                                                      \
-            const int n = pix >> (a.lgHs + a.lgWs);                                                   \
-            const int ih = 2 * ((pix >> a.lgWs) & (Hs - 1)) - 1 + kh, iw = 2 * (pix & (Ws - 1)) - 1 + kw; \
+            const int pix = b_pix[p];                                                                 \
+            const int y = pix >> a.lgWs;                       /* n * Hs + py */                       \
+            const int ih = 2 * (y & (Hs - 1)) - 1 + kh, iw = 2 * (pix & (Ws - 1)) - 1 + kw;           \
             const bool ok = pix < kend && (unsigned)ih < (unsigned)Hl && (unsigned)iw < (unsigned)Wl; \
-            const float* src = ok ? a_L + ((((size_t)n * Hl + ih) * Wl + iw) * Cl + lch) : a.zeros;   \
+            /* n * Hl + ih = 2 * y - 1 + kh: the large-image row index is linear in y */              \
+            const unsigned off = (((unsigned)(2 * y - 1 + kh) << lgWl) + (unsigned)iw) << a.lgCl;     \
+            const float* src = ok ? a_L + ((size_t)off + lch) : a.zeros;                              \
             rb[SET][p] = *reinterpret_cast<const f32x4*>(src);                                       \
+            b_pix[p] += BK;                                                                           \
         }                                                                                             \
     }
 #define WG_STORE_TILE(BUF, SET)                                                                       \
@@ -646,21 +662,28 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
         }                                                                                             \
         const float* pA = sA + (BUF) * BK * LDA + lh * LDA + wm * (32 * TM) + li;                     \
         const float* pB = sB + (BUF) * BK * LDB + lh * LDB + wn * (32 * TN) + li;                     \
-        float fa[2][TM], fb[2][TN];                                                                   \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = pA[32 * i];                         \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = pB[32 * j];                         \
-        _Pragma("unroll") for (int s = 0; s < BK / 2; ++s) {                                          \
-            const int cur = s & 1, nxt = cur ^ 1;                                                     \
-            if (s + 1 < BK / 2) {                                                                     \
-                _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[nxt][i] = pA[(2 * s + 2) * LDA + 32 * i]; \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[nxt][j] = pB[(2 * s + 2) * LDB + 32 * j]; \
+        /* fragments are fetched a chunk of four k-steps ahead of the MFMAs that use them (256 cycles of matrix-pipe time to   \
+           cover the LDS latency; one step ahead -- 64 cycles -- left every MFMA waiting for its operands) */                  \
+        float fa[2][4][TM], fb[2][4][TN];                                                             \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][q][i] = pA[(2 * q) * LDA + 32 * i];  \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][q][j] = pB[(2 * q) * LDB + 32 * j];  \
+        }                                                                                             \
+        _Pragma("unroll") for (int c = 0; c < BK / 8; ++c) {                                          \
+            const int cur = c & 1, nxt = cur ^ 1;                                                     \
+            if (c + 1 < BK / 8) {                                                                     \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                       \
+                    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[nxt][q][i] = pA[(8 * c + 8 + 2 * q) * LDA + 32 * i]; \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[nxt][q][j] = pB[(8 * c + 8 + 2 * q) * LDB + 32 * j]; \
+                }                                                                                     \
             }                                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                        \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0); \
-            if (s == 0) { ST }                                                                        \
-            if (s == 1) { LD }                                                                        \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                             \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                    \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][i], fb[cur][q][j], acc[i][j], 0, 0, 0); \
+            if (c == 0) { ST }                                                                        \
+            if (c == 1) { LD }                                                                        \
         }                                                                                             \
         __syncthreads();                                                                              \
     }
