@@ -243,41 +243,65 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     }
 
     // ---- epilogue ----------------------------------------------------------------------
+    // The accumulators go through LDS once (the main loop's last barrier has passed: the staging buffers are free) so that the
+    // fused arithmetic and the stores work on four consecutive channels per lane: a quarter of the store / aref-load
+    // instructions, each covering a row's BN * 4 contiguous bytes.  Same values, same operations per element.
     float* const outp = gridDim.y > 1 ? a.slab + (size_t)blockIdx.y * a.slab_stride : static_cast<float*>(a.out);
     const int epi = gridDim.y > 1 ? (int)EPI_RAW : a.epi;
+    constexpr int LDT = BN + 4;                      // 16-byte slots per row: odd multiple for BN = 32, 64, 128
+    static_assert(BM * LDT <= 2 * LD * (BM + BN), "output tile must fit the staging buffers");
+    float* const sT = smem;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m >= a.M) continue;
-            const int n = m >> (a.lgHr + a.lgWr);
-            size_t opix;
-            if (a.form == 0) {
-                opix = (size_t)m;
-            } else {
-                const int rh = (m >> a.lgWr) & (Hr - 1), rw = m & (Wr - 1);
-                opix = ((size_t)n * a.Ho + 2 * rh + ph) * a.Wo + 2 * rw + pw;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sT[(wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDT + wn * (32 * TN) + 32 * j + li] = acc[i][j][r];
+    __syncthreads();
+    constexpr int C4 = BN / 4, RPP = 256 / C4;       // float4 columns per row, rows per pass
+    const int c4 = tid % C4, r0 = tid / C4;
+    const int co = n0 + c4 * 4;
+    const f32x4 bias4 = epi == EPI_BIAS_LRELU_DROP ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    if (epi == EPI_AFFINE_RELU) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + co); sh4 = *reinterpret_cast<const f32x4*>(a.shift + co); }
+    const bool use_noise = (epi == EPI_BIAS_LRELU_DROP || epi == EPI_LRELU_BWD) && a.noise != nullptr;
+#pragma unroll
+    for (int p = 0; p < BM / RPP; ++p) {
+        const int row = r0 + RPP * p, m = m0 + row;
+        if (m >= a.M) continue;
+        const int n = m >> (a.lgHr + a.lgWr);
+        size_t opix;
+        if (a.form == 0) {
+            opix = (size_t)m;
+        } else {
+            const int rh = (m >> a.lgWr) & (Hr - 1), rw = m & (Wr - 1);
+            opix = ((size_t)n * a.Ho + 2 * rh + ph) * a.Wo + 2 * rw + pw;
+        }
+        const size_t o = opix * a.Co + co;
+        f32x4 v = *reinterpret_cast<const f32x4*>(sT + row * LDT + c4 * 4);
+        if (epi == EPI_BIAS_LRELU_DROP) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float t = v[e] + bias4[e]; v[e] = t > 0.f ? t : t * a.slope; }
+            if (use_noise) {
+                const f32x4 nz = *reinterpret_cast<const f32x4*>(a.noise + (size_t)n * a.Co + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= nz[e];
             }
+        } else if (epi == EPI_AFFINE_RELU) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int co = n0 + wn * (32 * TN) + 32 * j + li;
-                float v = acc[i][j][r];
-                const size_t o = opix * a.Co + co;
-                if (epi == EPI_BIAS_LRELU_DROP) {
-                    v += a.bias[co];
-                    v = v > 0.f ? v : v * a.slope;
-                    if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
-                } else if (epi == EPI_AFFINE_RELU) {
-                    v = fmaxf(fmaf(v, a.scale[co], a.shift[co]), 0.f);
-                } else if (epi == EPI_LRELU_BWD) {
-                    const float ar = static_cast<const float*>(a.aref)[o];
-                    v *= ar > 0.f ? 1.f : a.slope;
-                    if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
-                }
-                outp[o] = v;
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc4[e], sh4[e]), 0.f);
+        } else if (epi == EPI_LRELU_BWD) {
+            const f32x4 ar = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.aref) + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= ar[e] > 0.f ? 1.f : a.slope;
+            if (use_noise) {
+                const f32x4 nz = *reinterpret_cast<const f32x4*>(a.noise + (size_t)n * a.Co + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= nz[e];
             }
         }
+        *reinterpret_cast<f32x4*>(outp + o) = v;
     }
 }
 

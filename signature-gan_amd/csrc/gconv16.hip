@@ -161,16 +161,41 @@ __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
     }
 
     // ---- epilogue (fp32 arithmetic; the split-K slabs are fp32, the tensor itself is T) ------------------------
+    // The accumulators go through LDS (free after the loop's last barrier), 64 rows at a time, so that the fused arithmetic
+    // and the stores work on four consecutive channels per lane: 8-byte stores of T (16-byte ones into a slab) covering a
+    // row's contiguous bytes, instead of one 2-byte store per element.  Same values, same operations per element.
     const bool to_slab = gridDim.y > 1;
     float* const slab = a.slab + (size_t)blockIdx.y * a.slab_stride;
     T* const outp = reinterpret_cast<T*>(a.out);
     const T* const aref = reinterpret_cast<const T*>(a.aref);
     const int epi = to_slab ? (int)EPI_RAW : a.epi;
+    constexpr int LDT = BN + 4, SR = BM < 64 ? BM : 64, NPASS = BM / SR;
+    static_assert(SR * LDT * 4 <= 2 * LD * (BM + BN) * 2, "a 64-row slice of the output tile must fit the staging buffers");
+    float* const sT = reinterpret_cast<float*>(smem_raw);
+    constexpr int C4 = BN / 4, RPP = 256 / C4;
+    const int c4 = tid % C4, r0 = tid / C4;
+    const int co = n0 + c4 * 4;
+    const f32x4 bias4 = epi == EPI_BIAS_LRELU_DROP ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    if (epi == EPI_AFFINE_RELU) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + co); sh4 = *reinterpret_cast<const f32x4*>(a.shift + co); }
+    const bool use_noise = (epi == EPI_BIAS_LRELU_DROP || epi == EPI_LRELU_BWD) && a.noise != nullptr;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int q = 0; q < NPASS; ++q) {
+        if (q) __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        for (int i = 0; i < TM; ++i) {
+            const int rb = wm * (32 * TM) + 32 * i - q * SR;              // this wave's 32-row block inside the slice?
+            if (rb < 0 || rb >= SR) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sT[(rb + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDT + wn * (32 * TN) + 32 * j + li] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < SR / RPP; ++p) {
+            const int row = r0 + RPP * p, m = m0 + q * SR + row;
             if (m >= a.M) continue;
             const int n = m >> (a.lgHr + a.lgWr);
             size_t opix;
@@ -180,24 +205,30 @@ __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
                 const int rh = (m >> a.lgWr) & (Hr - 1), rw = m & (Wr - 1);
                 opix = ((size_t)n * a.Ho + 2 * rh + ph) * a.Wo + 2 * rw + pw;
             }
+            const size_t o = opix * a.Co + co;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sT + row * LDT + c4 * 4);
+            if (epi == EPI_BIAS_LRELU_DROP) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int co = n0 + wn * (32 * TN) + 32 * j + li;
-                float v = acc[i][j][r];
-                const size_t o = opix * a.Co + co;
-                if (epi == EPI_BIAS_LRELU_DROP) {
-                    v += a.bias[co];
-                    v = v > 0.f ? v : v * a.slope;
-                    if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
-                } else if (epi == EPI_AFFINE_RELU) {
-                    v = fmaxf(fmaf(v, a.scale[co], a.shift[co]), 0.f);
-                } else if (epi == EPI_LRELU_BWD) {
-                    const float ar = ld1<T>(aref + o);
-                    v *= ar > 0.f ? 1.f : a.slope;
-                    if (a.noise) v *= a.noise[(size_t)n * a.Co + co];
+                for (int e = 0; e < 4; ++e) { float t = v[e] + bias4[e]; v[e] = t > 0.f ? t : t * a.slope; }
+                if (use_noise) {
+                    const f32x4 nz = *reinterpret_cast<const f32x4*>(a.noise + (size_t)n * a.Co + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= nz[e];
                 }
-                if (to_slab) slab[o] = v; else st1<T>(outp + o, v);
+            } else if (epi == EPI_AFFINE_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc4[e], sh4[e]), 0.f);
+            } else if (epi == EPI_LRELU_BWD) {
+                const f32x4 ar = ld4<T>(aref + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= ar[e] > 0.f ? 1.f : a.slope;
+                if (use_noise) {
+                    const f32x4 nz = *reinterpret_cast<const f32x4*>(a.noise + (size_t)n * a.Co + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= nz[e];
+                }
             }
+            if (to_slab) *reinterpret_cast<f32x4*>(slab + o) = v; else st4<T>(outp + o, v);
         }
     }
 }
