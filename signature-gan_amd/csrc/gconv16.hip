@@ -35,7 +35,7 @@ template <> struct Mma<f16_t> {
     static __device__ __forceinline__ f32x16 run(V a, V b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-template <class T, int BM, int BN, int WM, int WN>
+template <class T, int BM, int BN, int WM, int WN, int NSET = 2>
 __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
     typedef typename Mma<T>::V Frag;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -99,25 +99,25 @@ __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
             a_step[p] = ok ? BK : 0;
         }
     };
-    s16x8 ra[PA], rb[PB];
-    auto load_tile = [&]() __attribute__((always_inline)) {
+    s16x8 ra[NSET][PA], rb[NSET][PB];    // register sets: tile t waits in set t % NSET
+    auto load_tile = [&](int set = 0) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            ra[p] = *reinterpret_cast<const s16x8*>(a_cur[p]);
+            ra[set][p] = *reinterpret_cast<const s16x8*>(a_cur[p]);
             a_cur[p] += a_step[p];
         }
 #pragma unroll
-        for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const s16x8*>(wcur + (size_t)(64 * p) * Ktot);
+        for (int p = 0; p < PB; ++p) rb[set][p] = *reinterpret_cast<const s16x8*>(wcur + (size_t)(64 * p) * Ktot);
         wcur += BK;
         if (++l_cc == (1 << lgcpt)) { l_cc = 0; ++l_tap; set_tap(); }
     };
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    auto store_tile = [&](int buf, int set = 0) __attribute__((always_inline)) {
         T* dA = sA + buf * LD * BM + (rloc & (BM - 1)) * LD + kc * 8;
         T* dB = sB + buf * LD * BN + (rloc & (BN - 1)) * LD + kc * 8;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) *reinterpret_cast<s16x8*>(dA + 64 * p * LD) = ra[p];
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<s16x8*>(dA + 64 * p * LD) = ra[set][p];
 #pragma unroll
-        for (int p = 0; p < PB; ++p) *reinterpret_cast<s16x8*>(dB + 64 * p * LD) = rb[p];
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<s16x8*>(dB + 64 * p * LD) = rb[set][p];
     };
 
     f32x16 acc[TM][TN];
@@ -128,16 +128,9 @@ __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nk > 0) {
-        set_tap();
-        load_tile();
-        store_tile(0);
-        if (nk > 1) load_tile();
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    // one K-tile out of LDS buffer `buf`; st: the LDS write of tile kt+1 out of register set `sset` rides along behind the first
+    // MFMAs, ld: the loads of a later tile into that set behind the second
+    auto tile = [&](const int buf, const int sset, const bool st, const bool ld) __attribute__((always_inline)) {
         const T* pA = sA + buf * LD * BM + (wm * (32 * TM) + li) * LD + 8 * lh;
         const T* pB = sB + buf * LD * BN + (wn * (32 * TN) + li) * LD + 8 * lh;
         Frag fa[2][TM], fb[2][TN];
@@ -154,10 +147,39 @@ __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fa[s][i], fb[s][j], acc[i][j]);
-            if (s == 0 && kt + 1 < nk) store_tile(buf ^ 1);     // tile kt+1: loaded a tile ago
-            if (s == 1 && kt + 2 < nk) load_tile();             // tile kt+2: lands during the next tile
+            if (s == 0 && st) store_tile(buf ^ 1, sset);
+            if (s == 1 && ld) load_tile(sset);
         }
         __syncthreads();
+    };
+    if (nk >= 2 * NSET + 1) {
+        // loads NSET tiles ahead, as in the fp32 kernel (gconv.hip): register set t % NSET, steady loop unrolled by NSET with
+        // unconditional loads so that the wait before the LDS write covers the oldest set only
+        set_tap();
+#pragma unroll
+        for (int t = 0; t < NSET; ++t) load_tile(t);
+        store_tile(0, 0);
+        load_tile(0);
+        __syncthreads();
+        int kt = 0;
+        for (; kt + NSET + NSET < nk; kt += NSET) {
+#pragma unroll
+            for (int h = 0; h < NSET; ++h) tile(h & 1, (h + 1) % NSET, true, true);
+        }
+        for (; kt < nk; kt += NSET) {
+#pragma unroll
+            for (int h = 0; h < NSET; ++h)
+                if (kt + h < nk) tile(h & 1, (h + 1) % NSET, kt + h + 1 < nk, kt + h + 1 + NSET < nk);
+        }
+    } else {
+        if (nk > 0) {
+            set_tap();
+            load_tile();
+            store_tile(0);
+            if (nk > 1) load_tile();
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) tile(kt & 1, 0, kt + 1 < nk, kt + 2 < nk);
     }
 
     // ---- epilogue (fp32 arithmetic; the split-K slabs are fp32, the tensor itself is T) ------------------------
