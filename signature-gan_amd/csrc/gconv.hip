@@ -31,8 +31,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WM, int WN, int BK = 32, int DEEP = 0>
-__global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
+// KQ = 2: two wave quads per workgroup, each running the whole pipeline on its own half of the workgroup's K range and its
+// own LDS buffers; the second quad's accumulators are added to the first's through LDS before the epilogue.  This is a
+// two-way K split WITHOUT slabs or a second kernel (sum order quad 0 + quad 1 = slab 0 + slab 1 of the split-K protocol:
+// bit-identical); used for the launches that would otherwise be split in two.
+template <int BM, int BN, int WM, int WN, int BK = 32, int DEEP = 0, int KQ = 1>
+__global__ __launch_bounds__(256 * KQ) void k_gconv(const GConvArgs a) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int PA = BM / 32, PB = BN / 32;
     constexpr int KC = BK / 32;        // 16-byte chunks a thread stages per row and K-tile
@@ -42,11 +46,12 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     // 16-byte slots because rows differ by 9 slots).  K is consumed in the permuted pairing
     // k = 8c + 4*(lane>>5) + t, identical for A and B, so only the fp32 summation order changes.
     constexpr int LD = BK + 4;
-    __shared__ __attribute__((aligned(16))) float smem[2 * LD * (BM + BN)];
-    float* const sA = smem;
-    float* const sB = smem + 2 * LD * BM;
+    __shared__ __attribute__((aligned(16))) float smem[KQ * 2 * LD * (BM + BN)];
+    const int quad = KQ > 1 ? (int)(threadIdx.x >> 8) : 0;
+    float* const sA = smem + quad * (2 * LD * (BM + BN));
+    float* const sB = sA + 2 * LD * BM;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // thread / wave index inside the quad
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const float* const a_in = static_cast<const float*>(a.in);
@@ -61,9 +66,10 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     const int Ktot = ntaps * a.Ci;
     const int lgcpt = 31 - __builtin_clz(a.Ci / BK);      // K-tiles per tap = Ci / 32, a power of two
     const int nk_all = ntaps << lgcpt;
-    // split-K: this block owns K-tiles [k_lo, k_hi)
-    const int kper = (nk_all + gridDim.y - 1) / gridDim.y;
-    const int k_lo = blockIdx.y * kper;
+    // split-K: this block (this quad of it) owns K-tiles [k_lo, k_hi); with KQ = 2 the launcher guarantees equal halves,
+    // so both quads pass the same number of barriers
+    const int kper = (nk_all + gridDim.y * KQ - 1) / (gridDim.y * KQ);
+    const int k_lo = (blockIdx.y * KQ + quad) * kper;
     const int k_hi = min(nk_all, k_lo + kper);
     const int nk = k_hi - k_lo;
 
@@ -251,14 +257,37 @@ __global__ __launch_bounds__(256) void k_gconv(const GConvArgs a) {
     constexpr int LDT = BN + 4;                      // 16-byte slots per row: odd multiple for BN = 32, 64, 128
     static_assert(BM * LDT <= 2 * LD * (BM + BN), "output tile must fit the staging buffers");
     float* const sT = smem;
+    if (KQ > 1) {                                    // quad 1's accumulators -> LDS -> added to quad 0's (lane-for-lane)
+        float* const red = smem + 2 * LD * (BM + BN);        // quad 1's own staging area
+        if (quad == 1) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sT[(wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDT + wn * (32 * TN) + 32 * j + li] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r) red[(((wave * TM + i) * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (quad == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(((wave * TM + i) * TN + j) * 16 + r) * 64 + lane];
+        }
+    }
+    if (quad == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sT[(wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDT + wn * (32 * TN) + 32 * j + li] = acc[i][j][r];
+    }
     __syncthreads();
+    if (quad != 0) return;
     constexpr int C4 = BN / 4, RPP = 256 / C4;       // float4 columns per row, rows per pass
     const int c4 = tid % C4, r0 = tid / C4;
     const int co = n0 + c4 * 4;
@@ -524,7 +553,7 @@ static double wgrad_bytes(const WgradArgs& a) {
     return es * ((double)a.K * a.Cs + 4.0 * a.K * a.Cl) + 4.0 * 16.0 * a.Cs * a.Cl;
 }
 
-template <int BM, int BN, int WM, int WN, int BKT = 32, int DEEP = 0>
+template <int BM, int BN, int WM, int WN, int BKT = 32, int DEEP = 0, int KQ = 1>
 static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
     const int ncls = a.form == 0 ? 1 : 4;
@@ -535,9 +564,9 @@ static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     if (a.dt != DT_F32) {
         launch_gconv16(id, a, grid, st, e0, e1);
     } else if (g_prof) {
-        hipExtLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT, DEEP>), grid, dim3(256), 0, st, e0, e1, 0, a);
+        hipExtLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT, DEEP, KQ>), grid, dim3(256 * KQ), 0, st, e0, e1, 0, a);
     } else {
-        hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT, DEEP>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT, DEEP, KQ>), grid, dim3(256 * KQ), 0, st, a);
     }
     if (nsplit > 1) {
         const int64_t total4 = (int64_t)a.B * a.Ho * a.Wo * a.Co / 4;
@@ -572,6 +601,9 @@ void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         // 128x64 middle size measured below 64x64 on every shape of the step (86 vs 93 TFLOP/s) and is not built
         if (a.Co >= 128 && blocks(128, 128) >= 512) return launch_cfg<128, 128, 2, 2, 32, 1>(a, st, 0, 1);
         const int ns = splits(blocks(64, 64));
+        // a two-way split runs as ONE launch of 8-wave workgroups (no slabs, no k_splitk_epilogue); nk is a power of two,
+        // so the halves are equal
+        if (ns == 2 && a.dt == DT_F32 && (nk & 1) == 0) return launch_cfg<64, 64, 2, 2, 32, 1, 2>(a, st, 2, 1);
         return launch_cfg<64, 64, 2, 2, 32, 1>(a, st, 2, ns);
     }
     if (a.dt == DT_F32 && a.form == 1 && a.Co == 32 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU) && (a.Ci == 32 || a.Ci == 64) &&
