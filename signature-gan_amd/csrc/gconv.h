@@ -72,7 +72,7 @@ extern Prof* g_prof;
 
 void launch_gconv(const GConvArgs& a, hipStream_t st);
 // 16-bit operand kernels (gconv16.hip); cfg: 0 = 128x128, 2 = 64x64, 3 = 128x32 tiles; e0 / e1: optional timing events
-void launch_gconv16(int cfg, const GConvArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+void launch_gconv16(int cfg, const GConvArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int kq = 1);
 void launch_wgrad16(bool small, const WgradArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 // fills a.dw (through the slabs + k_wgrad_reduce when K is split); returns the number of K splits
 // (slab must hold max_splits*Cs*(16*Cl + 1) floats)

@@ -562,7 +562,7 @@ static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     if (g_prof) g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, gconv_bytes(a), st);
     hipEvent_t e0 = g_prof ? g_prof->recs.back().e0 : nullptr, e1 = g_prof ? g_prof->recs.back().e1 : nullptr;
     if (a.dt != DT_F32) {
-        launch_gconv16(id, a, grid, st, e0, e1);
+        launch_gconv16(id, a, grid, st, e0, e1, KQ);
     } else if (g_prof) {
         hipExtLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT, DEEP, KQ>), grid, dim3(256 * KQ), 0, st, e0, e1, 0, a);
     } else {
@@ -603,7 +603,7 @@ void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         const int ns = splits(blocks(64, 64));
         // a two-way split runs as ONE launch of 8-wave workgroups (no slabs, no k_splitk_epilogue); nk is a power of two,
         // so the halves are equal
-        if (ns == 2 && a.dt == DT_F32 && (nk & 1) == 0) return launch_cfg<64, 64, 2, 2, 32, 1, 2>(a, st, 2, 1);
+        if (ns == 2 && (nk & 1) == 0) return launch_cfg<64, 64, 2, 2, 32, 1, 2>(a, st, 2, 1);
         return launch_cfg<64, 64, 2, 2, 32, 1>(a, st, 2, ns);
     }
     if (a.dt == DT_F32 && a.form == 1 && a.Co == 32 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU) && (a.Ci == 32 || a.Ci == 64) &&

@@ -35,17 +35,23 @@ template <> struct Mma<f16_t> {
     static __device__ __forceinline__ f32x16 run(V a, V b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-template <class T, int BM, int BN, int WM, int WN, int NSET = 2>
-__global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
+// KQ = 2: two wave quads per workgroup, each on its own half of the K range with its own LDS buffers, accumulators added
+// through LDS before the epilogue -- a two-way K split without slabs or a second kernel (see k_gconv in gconv.hip)
+template <class T, int BM, int BN, int WM, int WN, int NSET = 2, int KQ = 1>
+__global__ __launch_bounds__(256 * KQ) void k_gconv16(const GConvArgs a) {
     typedef typename Mma<T>::V Frag;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int PA = BM / 64 > 0 ? BM / 64 : 1, PB = BN / 64 > 0 ? BN / 64 : 1;   // staging passes (64 rows x 4 chunks per pass)
     constexpr int LD = BK + 8;                       // elements; 80-byte rows
-    __shared__ __attribute__((aligned(16))) unsigned short smem_raw[2 * LD * (BM + BN)];
-    T* const sA = reinterpret_cast<T*>(smem_raw);
+    constexpr int QUAD_SHORTS = 2 * LD * (BM + BN);
+    // (KQ = 2: the fp32 hand-over of quad 1's accumulators needs 64 lanes x 16 registers x 4 waves x 4 bytes per 32x32 block)
+    constexpr int RED_SHORTS = KQ > 1 ? TM * TN * 4 * 16 * 64 * 2 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned short smem_raw[KQ * QUAD_SHORTS > QUAD_SHORTS + RED_SHORTS ? KQ * QUAD_SHORTS : QUAD_SHORTS + RED_SHORTS];
+    const int quad = KQ > 1 ? (int)(threadIdx.x >> 8) : 0;
+    T* const sA = reinterpret_cast<T*>(smem_raw) + quad * QUAD_SHORTS;
     T* const sB = sA + 2 * LD * BM;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // thread / wave index inside the quad
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const T* const in = reinterpret_cast<const T*>(a.in);
@@ -60,8 +66,8 @@ __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
     const int Ktot = ntaps * a.Ci;
     const int lgcpt = 31 - __builtin_clz(a.Ci / BK);
     const int nk_all = ntaps << lgcpt;
-    const int kper = (nk_all + gridDim.y - 1) / gridDim.y;
-    const int k_lo = blockIdx.y * kper;
+    const int kper = (nk_all + gridDim.y * KQ - 1) / (gridDim.y * KQ);
+    const int k_lo = (blockIdx.y * KQ + quad) * kper;
     const int k_hi = min(nk_all, k_lo + kper);
     const int nk = k_hi - k_lo;
 
@@ -194,6 +200,26 @@ __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
     constexpr int LDT = BN + 4, SR = BM < 64 ? BM : 64, NPASS = BM / SR;
     static_assert(SR * LDT * 4 <= 2 * LD * (BM + BN) * 2, "a 64-row slice of the output tile must fit the staging buffers");
     float* const sT = reinterpret_cast<float*>(smem_raw);
+    if (KQ > 1) {                                    // quad 1's accumulators -> LDS -> added to quad 0's (lane-for-lane)
+        float* const red = reinterpret_cast<float*>(smem_raw + QUAD_SHORTS);
+        if (quad == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(((wave * TM + i) * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (quad == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(((wave * TM + i) * TN + j) * 16 + r) * 64 + lane];
+        }
+    }
     constexpr int C4 = BN / 4, RPP = 256 / C4;
     const int c4 = tid % C4, r0 = tid / C4;
     const int co = n0 + c4 * 4;
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int rb = wm * (32 * TM) + 32 * i - q * SR;              // this wave's 32-row block inside the slice?
-            if (rb < 0 || rb >= SR) continue;
+            if (rb < 0 || rb >= SR || quad != 0) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -218,7 +244,7 @@ __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
 #pragma unroll
         for (int p = 0; p < SR / RPP; ++p) {
             const int row = r0 + RPP * p, m = m0 + q * SR + row;
-            if (m >= a.M) continue;
+            if (m >= a.M || quad != 0) continue;
             const int n = m >> (a.lgHr + a.lgWr);
             size_t opix;
             if (a.form == 0) {
@@ -255,7 +281,12 @@ __global__ __launch_bounds__(256) void k_gconv16(const GConvArgs a) {
     }
 }
 
-void launch_gconv16(int cfg, const GConvArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+void launch_gconv16(int cfg, const GConvArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int kq) {
+    if (kq == 2) {          // 64x64 tiles, two-way K split inside the workgroup
+        if (a.dt == DT_BF16) hipExtLaunchKernelGGL((k_gconv16<bf16_t, 64, 64, 2, 2, 2, 2>), grid, dim3(512), 0, st, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL((k_gconv16<f16_t, 64, 64, 2, 2, 2, 2>), grid, dim3(512), 0, st, e0, e1, 0, a);
+        return;
+    }
 #define GC16(T, BM, BN, WM, WN) hipExtLaunchKernelGGL((k_gconv16<T, BM, BN, WM, WN>), grid, dim3(256), 0, st, e0, e1, 0, a)
     if (a.dt == DT_BF16) {
         if (cfg == 0) GC16(bf16_t, 128, 128, 2, 2); else if (cfg == 2) GC16(bf16_t, 64, 64, 2, 2); else GC16(bf16_t, 128, 32, 4, 1);
