@@ -237,12 +237,8 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv(const GConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
-#ifndef GCONV_ABLATE_STORE
             if (c == 0 && kt + 1 < nk) store_tile(buf ^ 1);     // tile kt+1: loaded a tile ago
-#endif
-#ifndef GCONV_ABLATE_LOAD
             if (c == 1 && kt + 2 < nk) load_tile();             // tile kt+2: lands during this tile
-#endif
         }
         __syncthreads();
     }

@@ -26,9 +26,13 @@ def _close(got, want, rtol=2e-4, what=""):
 
 # (batch, h_in, c_in, c_out) -- every conv layer shape of both model sizes, plus ragged batches
 DOWN = [(2, 32, 64, 128), (3, 16, 128, 256), (5, 8, 256, 512), (2, 8, 512, 512), (1, 64, 64, 128),
-        (2, 8, 128, 256), (2, 16, 64, 128), (2, 32, 32, 64), (1, 64, 32, 32), (128, 32, 64, 128)]
+        (2, 8, 128, 256), (2, 16, 64, 128), (2, 32, 32, 64), (1, 64, 32, 32), (128, 32, 64, 128),
+        # 256 tiles of 64x64: the two-way K split that runs inside 8-wave workgroups (no slabs)
+        (32, 32, 64, 128)]
 UP = [(2, 4, 256, 128), (3, 8, 128, 64), (2, 16, 64, 32), (1, 32, 32, 32), (2, 4, 512, 256), (1, 64, 32, 32),
       (3, 4, 512, 256), (2, 8, 256, 128), (2, 16, 128, 64), (64, 16, 128, 64),
+      # the in-workgroup two-way K split in the "up" form (64 tiles x 4 classes); four K-tiles only (the short, one-tile-ahead loop)
+      (64, 8, 128, 64), (2, 16, 32, 64),
       # large enough for k_gconv_up4 (all four parity classes per workgroup, input patch in LDS): row widths 16 / 32 / 64,
       # 32 and 64 input channels
       (192, 16, 32, 32), (48, 32, 32, 32), (12, 64, 32, 32), (96, 32, 64, 32), (24, 64, 64, 32)]
