@@ -180,8 +180,10 @@ __global__ __launch_bounds__(256) void k_colreduce(F f, int64_t R, int C, int cg
     const int64_t r0 = (int64_t)blockIdx.y * rows;
     const int64_t r1 = r0 + rows < R ? r0 + rows : R;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    if (c4 < C4)
-        for (int64_t r = r0 + lane; r < r1; r += rl) f(r, c4, C4, s0, s1);
+    if (c4 < C4) {
+#pragma unroll 8
+        for (int64_t r = r0 + lane; r < r1; r += rl) f(r, c4, C4, s0, s1);     // (unrolled: eight rows' loads in flight per lane)
+    }
     sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1;
     __syncthreads();
     if (lane == 0 && c4 < C4) {
