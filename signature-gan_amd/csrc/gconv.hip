@@ -490,8 +490,10 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int 
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
     }
     const int C4 = a.Co / 4;
-    const int c = (int)(i % C4) * 4;
-    const int64_t n = i / ((int64_t)C4 * a.Ho * a.Wo);
+    const int64_t per_img = (int64_t)C4 * a.Ho * a.Wo;
+    const bool p2 = (C4 & (C4 - 1)) == 0 && (per_img & (per_img - 1)) == 0;       // every layer: shifts instead of 64-bit divisions
+    const int c = (p2 ? (int)(i & (C4 - 1)) : (int)(i % C4)) * 4;
+    const int64_t n = p2 ? i >> (63 - __builtin_clzll(per_img)) : i / per_img;
     float* e = reinterpret_cast<float*>(&v);
     if (a.epi == EPI_BIAS_LRELU_DROP) {
 #pragma unroll

@@ -100,18 +100,36 @@ __global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
     if (q.type == PREP_PACK_DOWN || q.type == PREP_CLS) {
         const int I = q.type == PREP_CLS ? q.O : q.I;
         const float* src = q.src + (size_t)u * I * 16;
+#pragma unroll 4
         for (int e = tid; e < I * 16; e += 256) tile[(e >> 4) * 17 + (e & 15)] = src[e];
         __syncthreads();
         const size_t d0 = (size_t)u * I * 16;
-        for (int e = tid; e < I * 16; e += 256) { const int tap = e / I, i = e - tap * I; put_w(q, d0 + e, tile[i * 17 + tap]); }
+        if ((I & (I - 1)) == 0) {                  // channel counts are powers of two: shifts instead of a division per element
+            const int lgI = 31 - __builtin_clz(I);
+#pragma unroll 4
+            for (int e = tid; e < I * 16; e += 256) { const int tap = e >> lgI, i = e & (I - 1); put_w(q, d0 + e, tile[i * 17 + tap]); }
+        } else {
+            for (int e = tid; e < I * 16; e += 256) { const int tap = e / I, i = e - tap * I; put_w(q, d0 + e, tile[i * 17 + tap]); }
+        }
     } else if (q.type == PREP_PACK_UP) {
         const int I = q.I, O = q.O;
+#pragma unroll 4
         for (int e = tid; e < I * 16; e += 256) tile[(e >> 4) * 17 + (e & 15)] = q.src[((size_t)(e >> 4) * O + u) * 16 + (e & 15)];
         __syncthreads();
-        for (int e = tid; e < I * 16; e += 256) {
-            const int i = e % I, tt = (e / I) & 3, cls = e / (4 * I);
-            const int kh = 1 - (cls >> 1) + 2 * (tt >> 1), kw = 1 - (cls & 1) + 2 * (tt & 1);
-            put_w(q, ((size_t)cls * O + u) * 4 * I + tt * I + i, tile[i * 17 + kh * 4 + kw]);
+        if ((I & (I - 1)) == 0) {
+            const int lgI = 31 - __builtin_clz(I);
+#pragma unroll 4
+            for (int e = tid; e < I * 16; e += 256) {
+                const int i = e & (I - 1), tt = (e >> lgI) & 3, cls = e >> (lgI + 2);
+                const int kh = 1 - (cls >> 1) + 2 * (tt >> 1), kw = 1 - (cls & 1) + 2 * (tt & 1);
+                put_w(q, ((size_t)cls * O + u) * 4 * I + tt * I + i, tile[i * 17 + kh * 4 + kw]);
+            }
+        } else {
+            for (int e = tid; e < I * 16; e += 256) {
+                const int i = e % I, tt = (e / I) & 3, cls = e / (4 * I);
+                const int kh = 1 - (cls >> 1) + 2 * (tt >> 1), kw = 1 - (cls & 1) + 2 * (tt & 1);
+                put_w(q, ((size_t)cls * O + u) * 4 * I + tt * I + i, tile[i * 17 + kh * 4 + kw]);
+            }
         }
     } else if (q.type == PREP_FC_T) {            // K = q.O, C0 = q.I
         const int K = q.O, C0 = q.I, F = C0 * 16, kchunks = (K + 127) / 128;
@@ -290,7 +308,7 @@ __global__ void k_bn_relu(const T* __restrict__ y, T* __restrict__ a, int64_t n4
                           const float4* __restrict__ bn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    const int c = (int)(i % C4);
+    const int c = (C4 & (C4 - 1)) == 0 ? (int)(i & (C4 - 1)) : (int)(i % C4);      // (channel counts are powers of two)
     const float4 v = f4(ld4<T>(y + i * 4)), sc = bn[c], sh = bn[C4 + c];
     st4<T>(a + i * 4, f32x4{fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f),
                             fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), fmaxf(fmaf(v.w, sc.w, sh.w), 0.f)});
@@ -324,7 +342,7 @@ __global__ void k_bn_bwd_apply(T* __restrict__ da, const T* __restrict__ y, int6
                                const float4* __restrict__ bn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    const int c = (int)(i % C4);
+    const int c = (C4 & (C4 - 1)) == 0 ? (int)(i & (C4 - 1)) : (int)(i % C4);      // (channel counts are powers of two)
     const float4 g = f4(ld4<T>(da + i * 4)), yy = f4(ld4<T>(y + i * 4));
     const float4 sc = bn[c], sf = bn[C4 + c], mu = bn[2 * C4 + c], rs = bn[3 * C4 + c], c1 = bn[4 * C4 + c], c2 = bn[5 * C4 + c];
     float4 o;
