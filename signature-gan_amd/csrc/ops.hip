@@ -222,9 +222,14 @@ __device__ __forceinline__ void gather2(const float* __restrict__ p0, const floa
     float* const s0 = &sh[0][0][0];
     float* const s1 = &sh[1][0][0];
     float a = 0.f, b = 0.f;
-    if (c < C) {
-#pragma unroll 4
-        for (int k = rl; k < nch; k += nl) { a += p0[(size_t)k * C + c]; if (p1) b += p1[(size_t)k * C + c]; }
+    if (c < C) {            // (eight partial rows' loads in flight per lane; the sums keep their order)
+        if (p1) {
+#pragma unroll 8
+            for (int k = rl; k < nch; k += nl) { a += p0[(size_t)k * C + c]; b += p1[(size_t)k * C + c]; }
+        } else {
+#pragma unroll 8
+            for (int k = rl; k < nch; k += nl) a += p0[(size_t)k * C + c];
+        }
     }
     s0[rl * W + cl] = a; s1[rl * W + cl] = b;
     __syncthreads();
