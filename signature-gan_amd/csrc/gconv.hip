@@ -863,7 +863,7 @@ __global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__
     const bool live = !bias || idx < (size_t)Cs;
     float acc = 0.f;
     if (live) {
-#pragma unroll 4
+#pragma unroll 8
         for (int z = zl; z < nsplit; z += SL) acc += src[(size_t)z * zstride + idx];
     }
     if (SL > 1) {
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__
     }
     if (!live) return;
     if (bias) { db[idx] = acc; return; }
-    const int j = (int)(idx % N), s_ = (int)(idx / N);
+    const int j = (int)(idx & (size_t)(N - 1)), s_ = (int)(idx >> (4 + lgCl));      // N = 16 << lgCl
     const int tap = j >> lgCl, l = j & (Cl - 1);
     dw[((size_t)s_ * Cl + l) * 16 + tap] = acc;
 }
