@@ -141,12 +141,49 @@ def bench_mlp(args):
     m.close()
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): this process
+    becomes the launcher.  It starts N children -- the same command line, one rank each, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set as torch.distributed.run would set them -- relays rank 0's stdout (the ONE JSON line),
+    sends the other ranks' stdout to stderr, and exits with the worst child's code.  It never imports torch and never
+    touches HIP: a process that has initialised the GPU must not be the parent of the ranks' rendezvous, and must never
+    exec.  If a rank dies, the others (which would wait in a collective for ever) are terminated by PID."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                                  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs between processes on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                print(f"[bench] rank {r} exited with code {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in live:
+                    procs[q].terminate()
+        if live:
+            time.sleep(0.05)
+    return worst
+
+
 def pct(xs, q):
     xs = sorted(xs)
     return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
 
 
-def main():
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -165,10 +202,15 @@ def main():
                          "pass always uses, and the one to profile with rocprofv3 so per-kernel durations agree")
     ap.add_argument("--dist", action="store_true",
                     help="initialise torch.distributed (nccl) and the library's RCCL communicator even at world size 1")
+    ap.add_argument("--metrics-readback", default="late", choices=["late", "none"],
+                    help="late (default): every timed step's metrics are copied to pinned host memory asynchronously and read "
+                         "one step late, as the drop-in trainer does (SURVEY 8b: one read-back per step); none: never read")
     ap.add_argument("--host-allreduce", action="store_true",
                     help="N > 1: reduce the gradient buckets with torch.distributed between the step halves instead of the "
                          "library's own communicator (fallback / comparison)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.model == "conv":
+        return launch_ranks(args.gpus, argv)                     # before anything imports torch or touches the GPU
     if args.model == "mlp":
         args.size = args.size or 28
         return bench_mlp(args)
@@ -244,14 +286,30 @@ def main():
     # The loop hands each step the batch of the step after it as well (a prefetching loader has it):
     # that batch's D(real) forward then runs beside this step's Generator backward (siggan_stage_real).
     # Every step still does one D(real) forward -- for its successor instead of for itself.
-    for _ in range(args.warmup):
+    # One metrics read-back per step, as GANTrainer.train does it here: asynchronous copy of the 16 floats into
+    # pinned host memory behind the step, read on the host one step late (so the host is never more than a step ahead).
+    late = args.metrics_readback == "late"
+    host_m = [torch.empty(eng.metrics.numel(), dtype=torch.float32).pin_memory() for _ in range(2)]
+    host_ev = [torch.cuda.Event(), torch.cuda.Event()]
+    seen = {"n": 0, "d_loss": 0.0, "g_loss": 0.0}
+
+    def step(i):
         dp.step(real, next_real=real)
+        if late:
+            host_m[i & 1].copy_(eng.metrics, non_blocking=True)
+            host_ev[i & 1].record()
+            if i > 0:
+                host_ev[(i - 1) & 1].synchronize()
+                seen["n"] += 1; seen["d_loss"] += float(host_m[(i - 1) & 1][0]); seen["g_loss"] += float(host_m[(i - 1) & 1][8])
+
+    for i in range(args.warmup):
+        step(i)
     block_s = []
     for _ in range(max(1, args.blocks)):
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            dp.step(real, next_real=real)
+        for i in range(args.steps):
+            step(i)
         barrier()
         dt = time.perf_counter() - t0
         if grouped and world > 1:
@@ -346,6 +404,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{cfg_name}: reference conv G/D {size}x{size}x1, z={latent}, batch {batch} per GPU, {dtype}, n_critic=1",
                        "global_batch": batch * world, "parallelism": f"dp{world}",
+                       "metrics_readback": ("one per step, read one step late from pinned host memory (async copy + event), "
+                                            f"{seen['n']} read in this run") if late else "none",
                        "gradient_allreduce": None if world == 1 and not grouped else
                        ("library RCCL (siggan_comm_init)" if transport == "lib" else "torch.distributed between the step halves"
                         + (f" (fallback: {comm_note})" if comm_note else ""))},
@@ -367,4 +427,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

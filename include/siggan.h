@@ -17,8 +17,10 @@
  *   siggan_g_step            VanillaGAN.train_generator_step    vanilla_gan_model.py:254-306
  *                            == GANTrainer._train_generator     train_vanilla_gan_signatures.py:339-376
  *   siggan_d_grads/_apply,   the same two steps cut at the point where a data-parallel run
- *   siggan_g_grads/_apply    averages the flat gradient bucket across ranks (RCCL all-reduce
- *                            issued by the host between the two halves)
+ *   siggan_g_grads/_apply    averages the flat gradient bucket across ranks: with a communicator
+ *                            (siggan_comm_init) *_apply itself issues the ncclAllReduce on the
+ *                            step's stream ahead of the optimiser; without one, a host may reduce
+ *                            the bound gradient arena between the two halves
  *   siggan_op_*              single kernels of the path (operator-level tests / profiling)
  *
  * Conventions

@@ -552,10 +552,9 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
 // event record / wait pairs, so the same code runs eagerly and under stream capture (hipGraph).
 // ------------------------------------------------------------------------------------------
 static int lane_check(siggan_ctx* c) {
-    if (c->comm_err) {
-        const int e = c->comm_err; c->comm_err = 0;
-        return fail(SIGGAN_E_HIP, "ncclAllReduce of the gradient bucket failed: %s", rccl()->GetErrorString(e));
-    }
+    if (c->comm_err)      // sticky: the communicator is unusable and the replicas have diverged; cleared by siggan_comm_destroy
+        return fail(SIGGAN_E_HIP, "ncclAllReduce of the gradient bucket failed (the optimiser update was skipped): %s",
+                    rccl()->GetErrorString(c->comm_err));
     if (c->lane_err == hipSuccess) return SIGGAN_OK;
     const hipError_t e = c->lane_err; c->lane_err = hipSuccess;
     return fail(SIGGAN_E_HIP, "an event record / stream wait / prepare table of the step failed: %s", hipGetErrorString(e));
@@ -916,8 +915,12 @@ static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         // the data-parallel exchange: ONE sum all-reduce of the network's flat gradient bucket over RCCL, in place, on the
         // step's own stream (whatever runs on the side lanes -- the pipelined Generator forward behind the D bucket, the
         // staged D(real) forward behind the G bucket -- overlaps it); the mean is taken by the optimiser's multiplier
+        // a failed (or earlier failed) exchange leaves this rank's arena unreduced: the optimiser must not step on it --
+        // the update is skipped and lane_check hands the error to the caller (sticky: every later call returns it until
+        // siggan_comm_destroy)
+        if (c->comm_err) return;
         const int e = rccl()->AllReduce(g, g, (size_t)n, NCCL_FLOAT32, NCCL_SUM, c->comm, L.m);
-        if (e != NCCL_SUCCESS && !c->comm_err) c->comm_err = e;
+        if (e != NCCL_SUCCESS) { c->comm_err = e; return; }
         gs *= 1.0f / (float)c->comm_world;
     }
     if (clip) launch_grad_sumsq(g, n, c->dev, c->partial, L.m);
@@ -1061,6 +1064,10 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     // the speculative forward needs its own lane: without overlap (or under graph replay) it is skipped
     if (spec_g && ((c->mode & SIGGAN_MODE_OVERLAP) == 0 || (c->mode & SIGGAN_MODE_GRAPH) != 0 || g_prof != nullptr)) spec_g = false;
     const bool abl = c->variant == SIGGAN_STEP_ABLATION;
+    // spectral norm, trainer step: phase_d_grads_sn runs its passes one after the other on the main lane and has no
+    // pipelined Generator forward -- siggan_g_grads then runs the training forward itself (an explicit zg_dev waits in
+    // z_g, zg_stash)
+    if (c->sn && !abl) spec_g = false;
     if (abl) {                                 // one z per iteration: it belongs to the (single, training-mode) Generator forward
         if (zg_dev) return fail(SIGGAN_E_INVALID, "the ablation step has one latent batch per iteration: pass it as z_dev");
         zg_dev = z_dev; z_dev = nullptr; spec_g = true;
@@ -1298,7 +1305,7 @@ extern "C" int siggan_comm_destroy(siggan_ctx* c) {
     if (!c->comm) return SIGGAN_OK;
     HIPCHK(hipDeviceSynchronize());
     NCCLCHK(rccl()->CommDestroy(c->comm));
-    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1; c->comm_err = 0;
     return SIGGAN_OK;
 }
 extern "C" int32_t siggan_comm_world(const siggan_ctx* c) { return c ? c->comm_world : -1; }

@@ -43,15 +43,32 @@ def broadcast_state_(tensors, src=0, group=None):
 
 def init_library_comm(engine, rank=None, world=None):
     """Create the library's RCCL communicator over the ranks of the default process group (or a single-rank one):
-    rank 0 draws the id, the store of torch.distributed carries its 128 bytes to the others -- the only use of
-    torch.distributed on this path."""
+    rank 0 draws the id, torch.distributed carries its 128 bytes to the others -- the only use of torch.distributed on
+    this path.  ncclCommInitRank is collective, so a rank that cannot take part must be known BEFORE any rank enters it:
+    every rank first does the rank-independent part (resolve the RCCL entry points; drawing an id does that and is
+    harmless to throw away), the ranks vote with one MIN all-reduce, and only a unanimous group goes on -- otherwise
+    EVERY rank raises the same RuntimeError and the caller can fall back (bench.py does)."""
     grouped = dist.is_available() and dist.is_initialized()
     rank = (dist.get_rank() if grouped else 0) if rank is None else rank
     world = (dist.get_world_size() if grouped else 1) if world is None else world
-    box = [engine.comm_unique_id() if rank == 0 else None]
+    ok, uid, why = 1, None, ""
+    try:
+        uid = engine.comm_unique_id()
+    except Exception as exc:                                     # noqa: BLE001 -- voted on below
+        ok, why = 0, f"{type(exc).__name__}: {exc}"
     if grouped and world > 1:
+        on_gpu = dist.get_backend() == "nccl"
+        flag = torch.tensor([ok], dtype=torch.int32, device=engine.device if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            raise RuntimeError("the library RCCL communicator cannot be created on every rank"
+                               + (f" (this rank: {why})" if why else " (another rank failed)"))
+        box = [uid if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-    engine.comm_init(rank, world, box[0])
+        uid = box[0]
+    elif not ok:
+        raise RuntimeError(why)
+    engine.comm_init(rank, world, uid)
     return engine
 
 
@@ -75,6 +92,8 @@ class DataParallelStep:
         e = self.e
         state = [e.g_params, e.d_params, e.g_bn_mean, e.g_bn_var, e.g_bn_batches, e.g_exp_avg, e.g_exp_avg_sq,
                  e.d_exp_avg, e.d_exp_avg_sq, e.g_adam_steps, e.d_adam_steps]
+        if e.spectral_norm:        # weight_u / weight_v: each rank drew its own; sigma (hence W / sigma) must agree across replicas
+            state += [e.d_sn_u, e.d_sn_v]
         if self.transport == "lib":
             for t in state:
                 e.comm_broadcast(t, 0)

@@ -51,6 +51,40 @@ def masks_from(f, key, batch, size, passes):
     return [torch.from_numpy(m) for m in ms]
 
 
+def census_signs(f, step):
+    """The reference run's decisions on its near-zero activation inputs (fixture record '<step>/census/*', step = 'dstep' |
+    'gstep'; written by make_golden.ActTap) as the oracle's ``signs`` argument: one (flat NCHW index, positive) pair per
+    activation layer in call order -- D step: D(real) blocks then D(fake) blocks; G step: fc, G blocks, then D blocks."""
+    n = f[f"{step}/census/n"]
+    idx, val = f[f"{step}/census/idx"], f[f"{step}/census/val"]
+    out, o = [], 0
+    for k in n:
+        out.append((torch.from_numpy(idx[o:o + k].astype(np.int64)), torch.from_numpy(val[o:o + k] > 0)))
+        o += int(k)
+    return out
+
+
+def flips_vs_census(f, step, signs, keep=None):
+    """Decisions of another implementation (``signs``: full bool tensors per activation layer, NCHW order) that differ from the
+    reference run's on the census elements: list of (layer, flat index, the reference's value / layer max).  ``keep``: per
+    layer a (B, C) Dropout2d keep mask or None -- a decision inside a dropped plane carries no gradient and is not counted."""
+    n, amax = f[f"{step}/census/n"], f[f"{step}/census/absmax"]
+    idx, val = f[f"{step}/census/idx"], f[f"{step}/census/val"]
+    out, o = [], 0
+    for l, k in enumerate(n):
+        i, v = idx[o:o + k].astype(np.int64), val[o:o + k]
+        assert signs[l].numel() == int(f[f"{step}/census/numel"][l]), "activation layer order / shape differs from the fixture"
+        mine = signs[l].reshape(-1).numpy()[i]
+        for j in np.nonzero(mine != (v > 0))[0]:
+            if keep is not None and keep[l] is not None and signs[l].dim() == 4:
+                _, c, h, w = signs[l].shape
+                if float(keep[l][int(i[j]) // (c * h * w), (int(i[j]) // (h * w)) % c]) == 0.0:
+                    continue
+            out.append((l, int(i[j]), float(v[j] / amax[l])))
+        o += int(k)
+    return out
+
+
 def probe(t, name):
     a = t.detach().reshape(-1).cpu().numpy()
     return a[I.probe_idx(a.size, name)]

@@ -83,6 +83,47 @@ class MaskTap:
             h.remove()
 
 
+# An activation input within this fraction of its layer's largest magnitude is "near zero".  Two fp32 implementations of
+# these layers differ by ~1e-6 of the layer scale, and the parity tests fail any sign disagreement above 1e-5 of it, so 2e-5
+# covers every decision that may legitimately differ (1e-4 would store five times as many entries for nothing).
+CENSUS_REL = 2e-5
+
+
+class ActTap:
+    """Observe (never alter) the INPUT of the reference's activation modules (nn.ReLU generator_vanilla_gan.py:58-60,127;
+    nn.LeakyReLU discriminator_vanilla_gan.py:66-69) with forward PRE-hooks -- the modules are inplace, the pre-hook sees the
+    pre-activation -- and keep the census of its near-zero elements: flat (NCHW) index, value and the side of zero the
+    reference put it on.  Two correct fp32 implementations can only disagree on the sign of such an element, so the census is
+    what lets any other implementation be compared with THIS run decision for decision (tests: oracle(signs = census) must
+    reproduce the fixture on any host; the HIP path's decisions are counted against it directly)."""
+
+    def __init__(self, *nets):
+        self.layers = []
+        mods = [m for net in nets for m in net.modules() if isinstance(m, (nn.ReLU, nn.LeakyReLU))]
+        self.h = [m.register_forward_pre_hook(self._hook) for m in mods]
+
+    def _hook(self, mod, inp):
+        flat = inp[0].detach().reshape(-1)
+        amax = float(flat.abs().max())
+        idx = torch.nonzero(flat.abs() <= CENSUS_REL * amax).reshape(-1)
+        self.layers.append((idx.numpy().astype(np.int32), flat[idx].numpy().copy(), flat.numel(), amax))
+
+    def close(self):
+        for h in self.h:
+            h.remove()
+
+    def same_as(self, other):
+        return len(self.layers) == len(other.layers) and all(
+            np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:] for a, b in zip(self.layers, other.layers))
+
+    def store(self, tag, out):
+        out[f"{tag}/census/n"] = np.array([len(i) for i, _, _, _ in self.layers], np.int32)
+        out[f"{tag}/census/numel"] = np.array([n for _, _, n, _ in self.layers], np.int64)
+        out[f"{tag}/census/absmax"] = np.array([a for _, _, _, a in self.layers], np.float32)
+        out[f"{tag}/census/idx"] = np.concatenate([i for i, _, _, _ in self.layers]) if self.layers else np.zeros(0, np.int32)
+        out[f"{tag}/census/val"] = np.concatenate([v for _, v, _, _ in self.layers]) if self.layers else np.zeros(0, np.float32)
+
+
 def probes(prefix, named, out):
     for k, t in named.items():
         a = t.detach().reshape(-1).numpy()
@@ -208,24 +249,38 @@ def make(size, latent, B, full_image):
     assert len(tap.masks) == len(chans)
 
     # (v)-(vii) single steps from known states ------------------------------------------
+    # (the three variants share weights and inputs, hence the forward pass and its census: stored once, equality asserted)
+    census = {}
     for tag, warm, clip in (("warm", True, None), ("fresh", False, None), ("clip", True, CLIP)):
         m = fresh_model(size, latent, warm=warm)
         tap = MaskTap(m.discriminator)
+        acts = ActTap(m.discriminator)                      # D(real) blocks, then D(fake) blocks
         torch.manual_seed(SEED_TORCH + 1)
         if clip is None:
             met = m.train_discriminator_step(real, noise=z)
         else:
             met = d_step_clipped(m, real, z, clip)
-        tap.close()
-        assert len(tap.masks) == 2 * len(chans)
+        tap.close(); acts.close()
+        assert len(tap.masks) == 2 * len(chans) and len(acts.layers) == 2 * len(chans)
         out[f"dstep_{tag}/masks"] = I.pack_masks(tap.masks)
+        if "dstep" not in census:
+            census["dstep"] = acts
+            acts.store("dstep", out)
+        assert acts.same_as(census["dstep"]), "the D-step forward differs between the step variants"
         record_step(f"dstep_{tag}", m, m.discriminator, m.d_optimizer, met, out)
 
         m = fresh_model(size, latent, warm=warm)
+        acts = ActTap(m.generator, m.discriminator)         # G: fc, blocks; then D blocks
         if clip is None:
             met = m.train_generator_step(B, noise=z2)
         else:
             met = g_step_clipped(m, z2, clip)
+        acts.close()
+        assert len(acts.layers) == 2 * len(chans) + 1
+        if "gstep" not in census:
+            census["gstep"] = acts
+            acts.store("gstep", out)
+        assert acts.same_as(census["gstep"]), "the G-step forward differs between the step variants"
         record_step(f"gstep_{tag}", m, m.generator, m.g_optimizer, met, out, extra_buffers=True)
 
     # (viii) 3-step sequence (D then G each step), metrics only ---------------------------
@@ -246,7 +301,7 @@ def make(size, latent, B, full_image):
 
     out["meta"] = np.array(json.dumps({
         "torch": torch.__version__, "threads": torch.get_num_threads(), "size": size, "latent": latent,
-        "batch": B, "clip": CLIP,
+        "batch": B, "clip": CLIP, "census_rel": CENSUS_REL,
         "seeds": dict(state_g=SEED_STATE_G, state_d=SEED_STATE_D, adam_g=SEED_ADAM_G, adam_d=SEED_ADAM_D,
                       z=SEED_Z, real=SEED_REAL, torch=SEED_TORCH)}))
     path = os.path.join(HERE, f"golden_s{size}_b{B}.npz")
@@ -427,6 +482,8 @@ if __name__ == "__main__":
     make(128, 128, 4, full_image=False)
     make(128, 128, 32, full_image=False)
     make(64, 100, 128, full_image=False)          # BASELINE configs[3]: conv G/D 64x64, batch 128
+    if "--cases-only" in sys.argv:                # the five step fixtures only (e.g. after adding a record to them)
+        sys.exit(0)
     make_spectral_norm()
     make_ablation_step()
     make_spectral_norm_steps()

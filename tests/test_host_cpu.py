@@ -239,3 +239,45 @@ def test_mlp_oracle_matches_an_nn_module_restatement():
         # (a Linear bias in front of BatchNorm has a zero true gradient: Adam moves it by up to lr on rounding noise)
         tol = 2.5 * 2e-4 if k_.endswith("linear.bias") else 1e-5
         assert float((v.detach().float() - o_g[k_].float()).abs().max()) <= tol, k_
+
+
+def test_bench_gpus_n_launches_n_ranks_without_touching_the_gpu():
+    """`python bench.py --gpus N` (the driver's command: no torchrun around it) must start N ranks itself, and the launching
+    process must never initialise the GPU -- here: never even import torch.  Run in a fresh interpreter with torch made
+    un-importable and subprocess.Popen replaced by a recorder; the real multi-rank run is rehearsed on the GPU box
+    (SIGGAN_DIST_BACKEND=gloo, see profiles/)."""
+    import subprocess
+    script = r'''
+import json, os, sys
+sys.modules["torch"] = None                     # any `import torch` in the launcher raises ImportError
+os.environ.pop("WORLD_SIZE", None); os.environ.pop("RANK", None)
+sys.path.insert(0, %r)
+import bench
+seen = []
+class FakeProc:
+    def __init__(self, cmd, env=None, stdout=None):
+        seen.append({"cmd": cmd, "rank": env["RANK"], "local": env["LOCAL_RANK"], "world": env["WORLD_SIZE"],
+                     "addr": env["MASTER_ADDR"], "port": env["MASTER_PORT"], "own_stdout": stdout is None})
+        self.rc = 3 if os.environ.get("FAIL_RANK") == env["RANK"] else 0
+        self.terminated = False
+    def poll(self): return self.rc
+    def terminate(self): self.terminated = True
+import subprocess
+subprocess.Popen = FakeProc
+rc = bench.main(["--gpus", "4", "--steps", "7", "--warmup", "2"])
+print(json.dumps({"rc": rc, "seen": seen, "torch_imported": sys.modules.get("torch") is not None}))
+''' % ROOT
+    for fail in (None, "2"):
+        env = dict(os.environ, **({"FAIL_RANK": fail} if fail else {}))
+        env.pop("WORLD_SIZE", None)
+        out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=120)
+        assert out.returncode == 0, out.stderr
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+        assert not rec["torch_imported"]
+        assert rec["rc"] == (3 if fail else 0)
+        assert [r["rank"] for r in rec["seen"]] == ["0", "1", "2", "3"] == [r["local"] for r in rec["seen"]]
+        assert {r["world"] for r in rec["seen"]} == {"4"} and {r["addr"] for r in rec["seen"]} == {"127.0.0.1"}
+        assert len({r["port"] for r in rec["seen"]}) == 1
+        assert [r["own_stdout"] for r in rec["seen"]] == [True, False, False, False]     # ONE JSON line: rank 0's
+        for r in rec["seen"]:
+            assert r["cmd"][1].endswith("bench.py") and r["cmd"][2:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]

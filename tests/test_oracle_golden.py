@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import CASES, I, O, SEED, assert_close, load_golden, masks_from, oracle_states, probe
+from common import CASES, I, O, SEED, assert_close, census_signs, flips_vs_census, load_golden, masks_from, oracle_states, probe
 
 RT, AT = 1e-4, 1e-6
 
@@ -42,6 +42,8 @@ def test_forward_passes(size, latent, batch):
 
 
 def _check_step(f, tag, names, metrics, grads, sd, opt, bufs=None):
+    """The oracle was given the reference run's own near-zero sign decisions (fixture census), so what is compared is
+    arithmetic only: 1e-4 on every gradient norm and, relative to the tensor's scale, on every gradient / moment probe."""
     for k, v in metrics.items():
         key = f"{tag}/metric/{k}"
         if v is not None and key in f:
@@ -49,13 +51,14 @@ def _check_step(f, tag, names, metrics, grads, sd, opt, bufs=None):
     gn = np.array([float(grads[k].norm()) for k in names])
     ref_gn = f[f"{tag}/grad_norm"]
     gscale = float(max(np.abs(f[f"{tag}/grad/{k}"]).max() for k in names))     # network-wide grad scale
-    assert_close(gn, ref_gn, 1e-3, 1e-4 * float(ref_gn.max()), tag + " grad norms")
+    assert_close(gn, ref_gn, 1e-4, 1e-5 * float(ref_gn.max()), tag + " grad norms")
     for k, rn in zip(names, ref_gn):
         # a parameter whose gradient is mathematically zero (a bias in front of a train-mode
         # BatchNorm) carries rounding noise only: Adam turns that noise into +-lr-sized moves,
         # so its moments / weights are checked against that bound, not bit-for-bit.
         noise = rn < 1e-5 * float(ref_gn.max())
-        assert_close(probe(grads[k], k), f[f"{tag}/grad/{k}"], 1e-3, 1e-4 * gscale, f"{tag} grad {k}")
+        tscale = max(float(np.abs(f[f"{tag}/grad/{k}"]).max()), 1e-3 * gscale)
+        assert_close(probe(grads[k], k), f[f"{tag}/grad/{k}"], 0, 1e-4 * tscale, f"{tag} grad {k}")
         assert_close(probe(opt.m[k], k), f[f"{tag}/m/{k}"], 1e-3, 1e-4 * gscale, f"{tag} exp_avg {k}")
         assert_close(probe(opt.v[k], k), f[f"{tag}/v/{k}"], 1e-3, 1e-7 * gscale * gscale, f"{tag} exp_avg_sq {k}")
         assert_close(probe(sd[k], k), f[f"{tag}/w/{k}"], 1e-4, 2.5e-4 if noise else 2e-6, f"{tag} weight {k}")
@@ -77,17 +80,43 @@ def test_single_steps(size, latent, batch, tag):
     g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=(tag != "fresh"))
     masks = masks_from(f, f"dstep_{tag}/masks", batch, size, 2)
     nb = len(masks) // 2
-    met, grads = O.d_step(g_sd, d_sd, d_opt, real, z, masks[:nb], masks[nb:], size, clip=clip)
+    met, grads = O.d_step(g_sd, d_sd, d_opt, real, z, masks[:nb], masks[nb:], size, clip=clip, signs=census_signs(f, "dstep"))
     if clip is not None:
         assert met["d_grad_norm"] > clip, "fixture was meant to have clipping active"
     _check_step(f, f"dstep_{tag}", d_opt.names, met, grads, d_sd, d_opt)
 
     g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=(tag != "fresh"))
-    met, grads = O.g_step(g_sd, d_sd, g_opt, z2, size, clip=clip)
+    met, grads = O.g_step(g_sd, d_sd, g_opt, z2, size, clip=clip, signs=census_signs(f, "gstep"))
     if clip is not None:
         assert met["g_grad_norm"] > clip
     bufs = [k for k in g_sd if k not in g_opt.names]
     _check_step(f, f"gstep_{tag}", g_opt.names, met, grads, g_sd, g_opt, bufs)
+
+
+@pytest.mark.parametrize("size,latent,batch", [(64, 100, 64), (128, 128, 32)])
+def test_census_makes_the_oracle_host_independent(size, latent, batch):
+    """A different host / thread count changes torch's fp32 summation order, so the free-running oracle lands a handful of
+    near-zero activation inputs on the other side than the reference run did (16.7 M such inputs in the last Generator block
+    at 128x128 batch 32; |x| ~ 1e-8 of the layer scale) and its gradients move by 1e-4..1e-3: that is the reference's noise
+    against ITSELF.  Given the fixture's census the oracle must reproduce the fixture at 1e-4 whatever the thread count --
+    which is what lets the GPU box's CPU (another host) anchor the HIP path to the reference run."""
+    f, _ = load_golden(size, batch)
+    z2 = torch.from_numpy(I.gen_z(batch, latent, SEED["z"] + 1))
+    ref = f["gstep_warm/grad_norm"]
+    big = ref > 1e-5 * ref.max()
+    prev = torch.get_num_threads()
+    try:
+        torch.set_num_threads(3)
+        g_sd, d_sd, g_opt, _ = oracle_states(size, latent, warm=True)
+        rec = []
+        _, grads, _, _ = O.g_grads(dict(g_sd), d_sd, z2, size, signs=census_signs(f, "gstep"), record=rec)
+    finally:
+        torch.set_num_threads(prev)
+    gn = np.array([float(grads[k].norm()) for k in g_opt.names])
+    assert float((np.abs(gn - ref)[big] / ref[big]).max()) <= 1e-4
+    # every decision this run would have taken differently is in the census (nothing away from zero differs)
+    for l, i, v in flips_vs_census(f, "gstep", [x > 0 for x in rec]):
+        assert abs(v) <= 1e-5, (l, i, v)
 
 
 @pytest.mark.parametrize("size,latent,batch", CASES[:2])
