@@ -215,7 +215,9 @@ def g_forward(sd: Dict[str, Tensor], z: Tensor, training: bool, size: int,
     for i in range(n_blocks):
         p = f"upsample_blocks.{i}.block."
         x = qy(F.conv_transpose2d(x, q.w(sd[p + "0.weight"]), None, stride=2, padding=1))
-        x = q.a(_act(bn(x, p + "1."), 0.0, sg(i + 1), record))
+        x = _act(bn(x, p + "1."), 0.0, sg(i + 1), record)
+        if i + 1 < n_blocks or not training:
+            x = q.a(x)                  # (training: the last block's activation is re-derived from y by both of its readers, never stored)
         if i + 1 < n_blocks:            # the last block's activation gradient is consumed where it is formed, never stored
             x = q.g(x)
     x = F.conv2d(x, sd["final_conv.0.weight"], sd["final_conv.0.bias"], stride=1, padding=1)

@@ -10,7 +10,9 @@ import os
 import torch  # noqa: F401  (must be loaded before the library; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsiggan_hip.so")
+# SIGGAN_LIB_PATH: load another build of the same ABI (A/B measurements of kernel variants); it must exist -- a missing
+# library raises either way, there is nothing to fall back to
+LIB_PATH = os.environ.get("SIGGAN_LIB_PATH") or os.path.join(_HERE, "libsiggan_hip.so")
 ABI_VERSION = 3
 M_COUNT = 16
 METRIC_INDEX = {"d_loss": 0, "d_loss_real": 1, "d_loss_fake": 2, "d_real_mean": 3, "d_fake_mean": 4,

@@ -87,14 +87,20 @@ void launch_bn_relu(int dt, const void* y, void* a, int64_t R, int C, const floa
 void launch_bn_bwd(int dt, void* da, const void* y, int64_t R, int C, float* bn, float* partial,
                    float* dgamma, float* dbeta, int perm_c0, hipStream_t s);
 
-// final 3x3 conv (C->1) + tanh, and its backward pieces.  act: [B][S][S][C] NHWC, img [B][S][S]
-void launch_final_fwd(int dt, const void* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s);
-// backward of the last Generator block from dpre in one pass family: d(act) of the final conv (recomputed, never stored),
-// relu mask re-derived from y, BatchNorm statistics + apply -> dy; dgamma/dbeta written
-void launch_final_dgrad_bn_bwd(int dt, const float* dpre, const float* W, const void* y, void* dy, int B, int S, int C, float* bn,
-                               float* partial, float* dgamma, float* dbeta, hipStream_t s);
-void launch_final_wgrad(int dt, const float* dpre, const void* act, float* dW, float* db, float* partial, int B, int S,
-                        int C, hipStream_t s);
+// final 3x3 conv (C->1) + tanh, and its backward pieces.  act: [B][S][S][C] NHWC, img [B][S][S].
+// bn != nullptr (training): `act` is the last block's PRE-BatchNorm tensor y and bn its [scale | shift] table -- the
+// activation relu(fma(y, scale, shift)) is formed on load and never stored
+void launch_final_fwd(int dt, const void* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s,
+                      const float* bn = nullptr);
+// backward of the last Generator block from dpre.  (1) launch_final_bwd_reduce: ONE read of y gives the BatchNorm-backward sums
+// (d(act) of the final conv recomputed from dpre, never stored; relu mask re-derived from y) into `partial` AND the partial
+// rows of the final conv's weight / bias gradient (activation re-derived from y) into `partial_w`;  (2) launch_final_wgrad_fin:
+// dW / db from partial_w (any lane);  (3) launch_final_bn_bwd_apply: dgamma / dbeta + dy from `partial`
+void launch_final_bwd_reduce(int dt, const float* dpre, const float* W, const void* y, int B, int S, int C, const float* bn,
+                             float* partial, float* partial_w, hipStream_t s);
+void launch_final_wgrad_fin(const float* partial_w, float* dW, float* db, int B, int S, int C, hipStream_t s);
+void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* W, const void* y, void* dy, int B, int S, int C, float* bn,
+                               const float* partial, float* dgamma, float* dbeta, hipStream_t s);
 
 // ---- Discriminator pieces -----------------------------------------------------------------
 // first block (Cin = 1): x = two segments (x0: n < n0, x1: the rest), out [B][S/2][S/2][C]

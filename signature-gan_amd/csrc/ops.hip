@@ -531,9 +531,13 @@ __device__ __forceinline__ StripId strip_of(int sid, int S, int xi) {
     return r;
 }
 
-template <class T>
+// BN: `act` is the last block's PRE-BatchNorm tensor y and bn = [scale | shift]: the activation relu(fma(y, scale, shift))
+// (k_bn_relu's own expression) is formed on load and never stored -- in training mode nothing else reads it in the
+// forward pass, and the backward pass re-derives it from y as well (k_final_bwd_reduce).
+template <class T, bool BN>
 __global__ __launch_bounds__(256) void k_final_fwd(const T* __restrict__ act, const float* __restrict__ W,
-                                                   const float* __restrict__ b, float* __restrict__ img, int S) {
+                                                   const float* __restrict__ b, float* __restrict__ img, int S,
+                                                   const float* __restrict__ bn) {
     constexpr int RY = 4, C = 32;
     const int c4 = threadIdx.x & 7;
     const StripId t = strip_of<RY>(blockIdx.x, S, threadIdx.x >> 3);
@@ -544,6 +548,8 @@ __global__ __launch_bounds__(256) void k_final_fwd(const T* __restrict__ act, co
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f4v*>(sw9 + k * 36 + c4 * 4);
     const float bias = b[0];
+    f4v sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+    if (BN) { sc = ldg4(bn + c4 * 4); sf = ldg4(bn + C + c4 * 4); }
     const T* base = act + (size_t)t.n * S * S * C + c4 * 4;
     f4v v[RY + 2][3];
 #pragma unroll
@@ -552,7 +558,9 @@ __global__ __launch_bounds__(256) void k_final_fwd(const T* __restrict__ act, co
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int xx = t.x + d - 1, xc = clampi(xx, S - 1);
-            const f4v q = ld4<T>(base + ((size_t)yc * S + xc) * C);
+            f4v q = ld4<T>(base + ((size_t)yc * S + xc) * C);
+            if (BN) q = f4v{fmaxf(fmaf(q.x, sc.x, sf.x), 0.f), fmaxf(fmaf(q.y, sc.y, sf.y), 0.f),
+                            fmaxf(fmaf(q.z, sc.z, sf.z), 0.f), fmaxf(fmaf(q.w, sc.w, sf.w), 0.f)};
             v[r][d] = (yy == yc && xx == xc) ? q : f4v{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -570,9 +578,14 @@ __global__ __launch_bounds__(256) void k_final_fwd(const T* __restrict__ act, co
         if (c4 == 0) img[((size_t)t.n * S + t.y0 + r) * S + t.x] = tanhf(acc + bias);
     }
 }
-void launch_final_fwd(int dt, const void* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s) {
+void launch_final_fwd(int dt, const void* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s,
+                      const float* bn) {
     (void)C;                                            // host checks C == 32, S % 32 == 0
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_fwd<T>, dim3(B * (S / 4) * (S / 32)), dim3(256), 0, s, (const T*)act, W, b, img, S));
+    const dim3 grid(B * (S / 4) * (S / 32));
+    SIGGAN_DT_SWITCH(dt, T, {
+        if (bn) hipLaunchKernelGGL((k_final_fwd<T, true>), grid, dim3(256), 0, s, (const T*)act, W, b, img, S, bn);
+        else hipLaunchKernelGGL((k_final_fwd<T, false>), grid, dim3(256), 0, s, (const T*)act, W, b, img, S, bn);
+    });
 }
 
 // d(act)[y][x][c] = sum_{kh,kw} dpre[y + 1 - kh][x + 1 - kw] * W[c][kh][kw], for the 4 channels of a lane.
@@ -607,15 +620,23 @@ __device__ __forceinline__ f4v final_dact(const float (&d)[RY + 2][3], const f4v
     return acc;
 }
 
-// Backward through [final conv] <- relu <- BatchNorm of the last Generator block, stage 1: per-channel
-// sums of dy_relu and dy_relu * xhat (the relu mask is re-derived from y: a > 0 <=> fma(y, scale, shift) > 0,
-// the forward's own expression).  One partial row per block; k_bn_bwd_fin adds the rows.
+// Backward through [final conv] <- relu <- BatchNorm of the last Generator block, stage 1 -- ONE read of the pre-BatchNorm
+// tensor y serves both consumers of the block's output:
+//   * BatchNorm backward: per-channel sums of dy_relu and dy_relu * xhat, dy_relu = relu'(.) * d(act) with d(act) of the final
+//     conv recomputed from the 1-channel dpre (never stored) and the relu mask re-derived from y (a > 0 <=> fma(y, scale,
+//     shift) > 0, the forward's own expression);
+//   * the final conv's weight gradient dW[c][kh][kw] = sum act[n][y][x][c] * dpre[n][y - kh + 1][x - kw + 1], db = sum dpre,
+//     with act = relu(fma(y, scale, shift)) re-derived the same way (the activation tensor is not materialised in training).
+// A block walks 8-row strips (grid-stride), folds the 32 pixel lanes (shuffles inside a wave, LDS across the 4 waves, fixed
+// order) and writes one partial row per output family; k_bn_bwd_fin / k_rows_sum add the rows.
 template <class T>
-__global__ __launch_bounds__(256) void k_final_bnbwd_reduce(const float* __restrict__ dpre, const float* __restrict__ W,
-                                                            const T* __restrict__ y, const float* __restrict__ bn,
-                                                            float* __restrict__ p0, float* __restrict__ p1, int S, int nstrips) {
+__global__ __launch_bounds__(256) void k_final_bwd_reduce(const float* __restrict__ dpre, const float* __restrict__ W,
+                                                          const T* __restrict__ y, const float* __restrict__ bn,
+                                                          float* __restrict__ p0, float* __restrict__ p1,
+                                                          float* __restrict__ pw, int S, int nstrips) {
     constexpr int RY = 8, C = 32;
     __shared__ f4v sh[2][4][8];
+    __shared__ float shw[4][8][37];
     const int c4 = threadIdx.x & 7, wave = threadIdx.x >> 6;
     __shared__ __attribute__((aligned(16))) float sw9[9 * 36];     // W[c][tap] -> [tap][c] (row stride 36), one coalesced pass
     for (int i = threadIdx.x; i < 9 * 32; i += 256) sw9[(i % 9) * 36 + i / 9] = W[i];
@@ -625,6 +646,10 @@ __global__ __launch_bounds__(256) void k_final_bnbwd_reduce(const float* __restr
     for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f4v*>(sw9 + k * 36 + c4 * 4);
     const f4v sc = ldg4(bn + c4 * 4), sf = ldg4(bn + C + c4 * 4), mu = ldg4(bn + 2 * C + c4 * 4), rs = ldg4(bn + 3 * C + c4 * 4);
     f4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    f4v acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = f4v{0.f, 0.f, 0.f, 0.f};
+    float sdb = 0.f;
     for (int sid = blockIdx.x; sid < nstrips; sid += gridDim.x) {
         const StripId t = strip_of<RY>(sid, S, threadIdx.x >> 3);
         float d[RY + 2][3];
@@ -637,25 +662,54 @@ __global__ __launch_bounds__(256) void k_final_bnbwd_reduce(const float* __restr
         for (int r = 0; r < RY; ++r) {
             const f4v g = final_dact<RY>(d, w, r);
             const f4v v = yv[r];
-            const f4v m = {fmaf(v.x, sc.x, sf.x) > 0.f ? g.x : 0.f, fmaf(v.y, sc.y, sf.y) > 0.f ? g.y : 0.f,
-                           fmaf(v.z, sc.z, sf.z) > 0.f ? g.z : 0.f, fmaf(v.w, sc.w, sf.w) > 0.f ? g.w : 0.f};
+            const f4v pre = {fmaf(v.x, sc.x, sf.x), fmaf(v.y, sc.y, sf.y), fmaf(v.z, sc.z, sf.z), fmaf(v.w, sc.w, sf.w)};
+            const f4v m = {pre.x > 0.f ? g.x : 0.f, pre.y > 0.f ? g.y : 0.f, pre.z > 0.f ? g.z : 0.f, pre.w > 0.f ? g.w : 0.f};
             s0 += m;
             s1.x = fmaf(m.x, (v.x - mu.x) * rs.x, s1.x); s1.y = fmaf(m.y, (v.y - mu.y) * rs.y, s1.y);
             s1.z = fmaf(m.z, (v.z - mu.z) * rs.z, s1.z); s1.w = fmaf(m.w, (v.w - mu.w) * rs.w, s1.w);
+            const f4v a = {fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f), fmaxf(pre.z, 0.f), fmaxf(pre.w, 0.f)};
+            sdb += d[r + 1][1];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float gg = d[r + 2 - kh][2 - kw];
+                    f4v& q = acc[kh * 3 + kw];
+                    q.x = fmaf(a.x, gg, q.x); q.y = fmaf(a.y, gg, q.y); q.z = fmaf(a.z, gg, q.z); q.w = fmaf(a.w, gg, q.w);
+                }
         }
     }
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {
         s0.x += __shfl_xor(s0.x, o); s0.y += __shfl_xor(s0.y, o); s0.z += __shfl_xor(s0.z, o); s0.w += __shfl_xor(s0.w, o);
         s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            acc[k].x += __shfl_xor(acc[k].x, o); acc[k].y += __shfl_xor(acc[k].y, o);
+            acc[k].z += __shfl_xor(acc[k].z, o); acc[k].w += __shfl_xor(acc[k].w, o);
+        }
+        sdb += __shfl_xor(sdb, o);
     }
-    if ((threadIdx.x & 63) < 8) { sh[0][wave][c4] = s0; sh[1][wave][c4] = s1; }
+    if ((threadIdx.x & 63) < 8) {
+        sh[0][wave][c4] = s0; sh[1][wave][c4] = s1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            shw[wave][c4][0 * 9 + k] = acc[k].x; shw[wave][c4][1 * 9 + k] = acc[k].y;
+            shw[wave][c4][2 * 9 + k] = acc[k].z; shw[wave][c4][3 * 9 + k] = acc[k].w;
+        }
+        shw[wave][c4][36] = sdb;
+    }
     __syncthreads();
     if (threadIdx.x < 8) {
         const f4v a = ((sh[0][0][c4] + sh[0][1][c4]) + sh[0][2][c4]) + sh[0][3][c4];
         const f4v b = ((sh[1][0][c4] + sh[1][1][c4]) + sh[1][2][c4]) + sh[1][3][c4];
         *reinterpret_cast<f4v*>(p0 + (size_t)blockIdx.x * C + c4 * 4) = a;
         *reinterpret_cast<f4v*>(p1 + (size_t)blockIdx.x * C + c4 * 4) = b;
+    }
+    float* out = pw + (size_t)blockIdx.x * (C * 9 + 1);
+    for (int o = threadIdx.x; o < C * 9 + 1; o += 256) {
+        const int g = o < C * 9 ? o / 36 : 0, j = o < C * 9 ? o % 36 : 36;     // channel c = 4*g + j/9, tap j%9
+        out[o] = ((shw[0][g][j] + shw[1][g][j]) + shw[2][g][j]) + shw[3][g][j];
     }
 }
 // stage 2 (after k_bn_bwd_fin): dy = scale * (dy_relu - c1 - xhat * c2), written to dy[B][S][S][C]
@@ -692,87 +746,6 @@ __global__ __launch_bounds__(256) void k_final_bnbwd_apply(const float* __restri
         st4<T>(dy + o0 + (size_t)r * S * C, o);
     }
 }
-void launch_final_dgrad_bn_bwd(int dt, const float* dpre, const float* W, const void* y, void* dy, int B, int S, int C, float* bn,
-                               float* partial, float* dgamma, float* dbeta, hipStream_t s) {
-    const int nstrips = B * (S / 4) * (S / 32), nstrips8 = nstrips / 2;          // apply: 4-row strips, reduce: 8-row strips
-    const int nch = nstrips8 < 1024 ? nstrips8 : 1024;
-    float* p0 = partial; float* p1 = partial + (size_t)nch * C;
-    SIGGAN_DT_SWITCH(dt, T, {
-        hipLaunchKernelGGL(k_final_bnbwd_reduce<T>, dim3(nch), dim3(256), 0, s, dpre, W, (const T*)y, bn, p0, p1, S, nstrips8);
-        launch_bn_bwd_fin(p0, p1, nch, (int64_t)B * S * S, C, bn, dgamma, dbeta, 0, s);
-        hipLaunchKernelGGL(k_final_bnbwd_apply<T>, dim3(nstrips), dim3(256), 0, s, dpre, W, (const T*)y, bn, (T*)dy, S);
-    });
-}
-
-// dW[c][kh][kw] = sum act[n][y][x][c] * dpre[n][y - kh + 1][x - kw + 1];  db = sum dpre.
-// Each block walks strips (grid-stride), keeps 9 x 4 weight sums + the bias sum per thread, folds the
-// 32 pixel lanes (shuffles inside a wave, LDS across the 4 waves, fixed order) and writes one
-// partial row [C*9 + 1]; k_rows_sum adds the rows.
-template <class T>
-__global__ __launch_bounds__(256) void k_final_wgrad(const float* __restrict__ dpre, const T* __restrict__ act,
-                                                     float* __restrict__ partial, int S, int nstrips) {
-    constexpr int RY = 8, C = 32;
-    __shared__ float sh[4][8][37];
-    const int c4 = threadIdx.x & 7, wave = threadIdx.x >> 6;
-    f4v acc[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] = f4v{0.f, 0.f, 0.f, 0.f};
-    float sdb = 0.f;
-    for (int sid = blockIdx.x; sid < nstrips; sid += gridDim.x) {
-        const StripId t = strip_of<RY>(sid, S, threadIdx.x >> 3);
-        const float* dbase = dpre + (size_t)t.n * S * S;
-        const T* abase = act + (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
-        float d[RY + 2][3];
-#pragma unroll
-        for (int r = 0; r < RY + 2; ++r) {
-            const int yy = t.y0 + r - 1, yc = clampi(yy, S - 1);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int xx = t.x + k - 1, xc = clampi(xx, S - 1);
-                const float q = dbase[yc * S + xc];
-                d[r][k] = (yy == yc && xx == xc) ? q : 0.f;
-            }
-        }
-        f4v a[RY];
-#pragma unroll
-        for (int r = 0; r < RY; ++r) a[r] = ld4<T>(abase + (size_t)r * S * C);
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            sdb += d[r + 1][1];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const float g = d[r + 2 - kh][2 - kw];
-                    f4v& q = acc[kh * 3 + kw];
-                    q.x = fmaf(a[r].x, g, q.x); q.y = fmaf(a[r].y, g, q.y); q.z = fmaf(a[r].z, g, q.z); q.w = fmaf(a[r].w, g, q.w);
-                }
-        }
-    }
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            acc[k].x += __shfl_xor(acc[k].x, o); acc[k].y += __shfl_xor(acc[k].y, o);
-            acc[k].z += __shfl_xor(acc[k].z, o); acc[k].w += __shfl_xor(acc[k].w, o);
-        }
-        sdb += __shfl_xor(sdb, o);
-    }
-    if ((threadIdx.x & 63) < 8) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            sh[wave][c4][0 * 9 + k] = acc[k].x; sh[wave][c4][1 * 9 + k] = acc[k].y;
-            sh[wave][c4][2 * 9 + k] = acc[k].z; sh[wave][c4][3 * 9 + k] = acc[k].w;
-        }
-        sh[wave][c4][36] = sdb;
-    }
-    __syncthreads();
-    float* out = partial + (size_t)blockIdx.x * (C * 9 + 1);
-    for (int o = threadIdx.x; o < C * 9 + 1; o += 256) {
-        const int g = o < C * 9 ? o / 36 : 0, j = o < C * 9 ? o % 36 : 36;     // channel c = 4*g + j/9, tap j%9
-        out[o] = ((sh[0][g][j] + sh[1][g][j]) + sh[2][g][j]) + sh[3][g][j];
-    }
-}
 __global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ partial, int nch, int width, float* __restrict__ o0, int n0,
                            float* __restrict__ o1) {
     // out[j] = sum_k partial[k][j];  j < n0 -> o0[j], else o1[j - n0]
@@ -783,12 +756,23 @@ __global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ par
     if (threadIdx.x >= 64 || j >= width) return;
     if (j < n0) o0[j] = s; else o1[j - n0] = s;
 }
-void launch_final_wgrad(int dt, const float* dpre, const void* act, float* dW, float* db, float* partial, int B, int S, int C,
-                        hipStream_t s) {
-    const int nstrips = B * (S / 8) * (S / 32);
-    const int nch = nstrips < 1024 ? nstrips : 1024;
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_wgrad<T>, dim3(nch), dim3(256), 0, s, dpre, (const T*)act, partial, S, nstrips));
-    hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 64)), dim3(1024), 0, s, partial, nch, C * 9 + 1, dW, C * 9, db);
+static int final_reduce_rows(int B, int S) { const int n8 = B * (S / 8) * (S / 32); return n8 < 1024 ? n8 : 1024; }
+void launch_final_bwd_reduce(int dt, const float* dpre, const float* W, const void* y, int B, int S, int C, const float* bn,
+                             float* partial, float* partial_w, hipStream_t s) {
+    const int nstrips8 = B * (S / 8) * (S / 32), nch = final_reduce_rows(B, S);
+    float* p0 = partial; float* p1 = partial + (size_t)nch * C;
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_bwd_reduce<T>, dim3(nch), dim3(256), 0, s, dpre, W, (const T*)y, bn, p0, p1,
+                                                partial_w, S, nstrips8));
+}
+void launch_final_wgrad_fin(const float* partial_w, float* dW, float* db, int B, int S, int C, hipStream_t s) {
+    hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 64)), dim3(1024), 0, s, partial_w, final_reduce_rows(B, S), C * 9 + 1, dW, C * 9, db);
+}
+void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* W, const void* y, void* dy, int B, int S, int C, float* bn,
+                               const float* partial, float* dgamma, float* dbeta, hipStream_t s) {
+    const int nstrips = B * (S / 4) * (S / 32), nch = final_reduce_rows(B, S);
+    const float* p0 = partial; const float* p1 = partial + (size_t)nch * C;
+    launch_bn_bwd_fin(p0, p1, nch, (int64_t)B * S * S, C, bn, dgamma, dbeta, 0, s);
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_bnbwd_apply<T>, dim3(nstrips), dim3(256), 0, s, dpre, W, (const T*)y, bn, (T*)dy, S));
 }
 
 // =========================================================================================

@@ -174,6 +174,8 @@ struct siggan_ctx {
     int dreal_B;         // batch whose D(real) forward siggan_g_grads already enqueued on lane c (0: none)
     int zg_stash;        // batch of an explicit G-step z handed to siggan_step_begin when the forward was not pipelined
     int g_fwd_pending;   // batch of a Generator training forward already enqueued by siggan_step_begin (0: none)
+    int ga_last_B;       // batch of the last TRAINING Generator forward: the last block's activation was not materialised
+                         // (siggan_debug_tensor("g_a", Lg) forms it on demand)
     hipEvent_t ev[NEV], ev_bridge[2];
     int evi;
     std::vector<std::pair<PhaseKey, hipGraphExec_t>> graphs;
@@ -359,6 +361,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1; c->comm_err = 0;
     c->g_fwd_pending = 0;
     c->zg_stash = 0;
+    c->ga_last_B = 0;
     for (int i = 0; i < siggan_ctx::NEV; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_bridge[i], hipEventDisableTiming));
     *out = c;
@@ -621,13 +624,19 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
             launch_bn_train_stats(c->dt, c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
                                   c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
                                   BN_MOMENTUM, BN_EPS, s);
-            launch_bn_relu(c->dt, c->g_y[l], c->g_a[l], R, C, c->g_bn[l], s);
+            // the LAST block's activation has two readers, the final conv here and its weight gradient in the backward
+            // pass: both re-derive it from y and this table, so it is never written (33.5 MB each way at batch 64)
+            if (l < c->Lg) launch_bn_relu(c->dt, c->g_y[l], c->g_a[l], R, C, c->g_bn[l], s);
         } else {
             a.out = c->g_a[l]; a.epi = EPI_AFFINE_RELU; a.scale = c->g_bne[l]; a.shift = c->g_bne[l] + C;
             launch_gconv(a, s);
         }
     }
-    launch_final_fwd(c->dt, c->g_a[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
+    if (training)
+        launch_final_fwd(c->dt, c->g_y[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s, c->g_bn[c->Lg]);
+    else
+        launch_final_fwd(c->dt, c->g_a[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
+    c->ga_last_B = training ? B : 0;
 }
 
 // Discriminator conv blocks + classifier logits for nB images written to workspace rows
@@ -710,15 +719,17 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
 // BatchNorm backward and the input-gradient chain; lane a: the weight gradients.
 static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     const int Lg = c->Lg, S = c->S;
-    L.fork(L.b);
-    launch_final_wgrad(c->dt, c->dpre, c->g_a[Lg], GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), c->partial_b, B, S, c->gC[Lg], L.b);
     for (int l = Lg; l >= 1; --l) {
         const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
         const int64_t R = (int64_t)B * Ho * Ho;
-        if (l == Lg)     // final conv's input-gradient folded into this block's BatchNorm backward
-            launch_final_dgrad_bn_bwd(c->dt, c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
+        if (l == Lg) {   // final conv's input-gradient folded into this block's BatchNorm backward; its weight gradient rides in
+                         // the same pass over y (the row sums of that gradient go to lane b)
+            launch_final_bwd_reduce(c->dt, c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b, L.m);
+            L.fork(L.b);
+            launch_final_wgrad_fin(c->partial_b, GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), B, S, Co, L.b);
+            launch_final_bn_bwd_apply(c->dt, c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
                                       GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
-        else
+        } else
             launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m);
         L.fork(L.a);                                       // dy[l] is complete on m here
         // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
@@ -1375,6 +1386,13 @@ extern "C" int siggan_debug_tensor(siggan_ctx* c, const char* name, int32_t idx,
     else return fail(SIGGAN_E_INVALID, "unknown debug tensor %s[%d]", name, idx);
     if (n > capv) return fail(SIGGAN_E_INVALID, "debug tensor %s[%d] holds %lld floats, %lld asked", name, idx, (long long)capv, (long long)n);
     DevGuard dg_(c->cfg.device); HIPCHK(dg_.err);
+    if (!strcmp(name, "g_a") && idx == c->Lg && c->ga_last_B) {
+        // after a training forward the last block's activation exists only as y + the BatchNorm table: form it now
+        const int64_t H = c->S;
+        HIPCHK(hipDeviceSynchronize());
+        launch_bn_relu(c->dt, c->g_y[idx], c->g_a[idx], (int64_t)c->ga_last_B * H * H, c->gC[idx], c->g_bn[idx], (hipStream_t)stream);
+        LAUNCHCHK();
+    }
     if (typed && c->dt != DT_F32) { launch_to_f32(c->dt, src, out_dev, n, (hipStream_t)stream); LAUNCHCHK(); }
     else HIPCHK(hipMemcpyAsync(out_dev, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SIGGAN_OK;
