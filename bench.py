@@ -376,6 +376,31 @@ def main(argv=None):
                                                     "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
                                                     "algorithmic_gbps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in recs}},
         }
+    secondary = None
+    if rank == 0 and not args.no_roofline:
+        # generation throughput (Generator.forward in eval mode, vanilla_gan_model.py:338-371) beside the headline,
+        # same engine / weights / batch; MFMA kernels stamped one at a time as above (profiles/secondary.py has the wider table)
+        gflop = {64: 87.06e6, 128: 414.19e6}[size] + 2 * (4096 if size == 64 else 8192) * (latent - (100 if size == 64 else 128))
+        zgen = torch.randn(batch, latent, device=dev)
+        for _ in range(10):
+            eng.g_forward(zgen, training=False)
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        for _ in range(100):
+            eng.g_forward(zgen, training=False)
+        torch.cuda.synchronize(dev); tg = (time.perf_counter() - t0) / 100
+        eng.set_mode(graph=False, overlap=False)
+        eng.prof_enable(True)
+        for _ in range(50):
+            eng.g_forward(zgen, training=False)
+        grecs = eng.prof_read()
+        eng.prof_enable(False)
+        eng.set_mode(graph=False, overlap=not args.serialize)
+        secondary = {"generation": {"metric": f"generated images/sec (G eval forward, bs{batch} {size}x{size})", "value": round(batch / tg, 0),
+                                    "us_per_batch": round(tg * 1e6, 1), "tflops": round(gflop * batch / tg / 1e12, 1),
+                                    "frac_of_mfma_peak": round(gflop * batch / tg / 1e12 / peak, 4),
+                                    "mfma_kernels_per_batch": {r["name"]: {"launches": r["launches"] / 50, "us": round(1e3 * r["ms"] / 50, 2),
+                                                                           "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1)} for r in grecs},
+                                    "mfma_us_per_batch": round(sum(1e3 * r["ms"] for r in grecs) / 50, 1)}}
     if grouped:
         dist.barrier()
 
@@ -416,7 +441,7 @@ def main(argv=None):
             "achieved_tflops_whole_step": round(imgs / dt * fpi / 1e12, 3),
             "frac_of_mfma_peak_whole_step": round(imgs / dt * fpi / 1e12 / (peak * world), 4),
             "final_metrics": {"d_loss": round(float(m[0]), 4), "g_loss": round(float(m[8]), 4)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }
         if dtype == "f32":
             out["frac_of_fp32_mfma_peak_whole_step"] = out["frac_of_mfma_peak_whole_step"]

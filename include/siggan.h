@@ -78,7 +78,11 @@ typedef struct siggan_config {
                              * gradients / Adam.  Every caller-visible tensor stays fp32 in all modes. */
     float   f16_grad_scale; /* F16 only: power-of-two factor carried by the backward chains so that small activation
                              * gradients stay above the fp16 subnormals; removed again inside the optimiser step (the bound
-                             * *_grads arenas hold scale x gradient between *_grads and *_apply).  0 = default (1024). */
+                             * *_grads arenas hold scale x gradient between *_grads and *_apply).  0 = default (1024).
+                             * The scale is STATIC (no dynamic loss scaling).  Protection against an overflow: in F16 mode
+                             * *_apply takes the gradient arena's sum of squares first, and when it is not finite (an inf / NaN
+                             * activation gradient reached a weight gradient) the whole update is SKIPPED -- parameters, moments
+                             * and step counts untouched -- and SIGGAN_M_D_SKIPPED / SIGGAN_M_G_SKIPPED is set to 1 (else 0). */
     int32_t spectral_norm;  /* != 0: torch.nn.utils.spectral_norm on every Discriminator conv and on the classifier
                              * (Discriminator(use_spectral_norm=True), discriminator_vanilla_gan.py:60-62,200-202): the d_params
                              * arena then holds weight_orig, siggan_storage.d_sn_u / d_sn_v the weight_u / weight_v buffers; every
@@ -117,6 +121,7 @@ enum {
     SIGGAN_M_D_LOSS = 0, SIGGAN_M_D_LOSS_REAL, SIGGAN_M_D_LOSS_FAKE, SIGGAN_M_D_REAL_MEAN,
     SIGGAN_M_D_FAKE_MEAN, SIGGAN_M_D_REAL_ACC, SIGGAN_M_D_FAKE_ACC, SIGGAN_M_D_GRAD_NORM,
     SIGGAN_M_G_LOSS, SIGGAN_M_G_FAKE_MEAN, SIGGAN_M_G_GRAD_NORM,
+    SIGGAN_M_D_SKIPPED, SIGGAN_M_G_SKIPPED,    /* F16 only: 1 when the update was skipped for a non-finite gradient, else 0 */
     SIGGAN_M_COUNT = 16
 };
 

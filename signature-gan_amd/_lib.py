@@ -17,7 +17,7 @@ ABI_VERSION = 3
 M_COUNT = 16
 METRIC_INDEX = {"d_loss": 0, "d_loss_real": 1, "d_loss_fake": 2, "d_real_mean": 3, "d_fake_mean": 4,
                 "d_real_acc": 5, "d_fake_acc": 6, "d_grad_norm": 7, "g_loss": 8, "g_fake_mean": 9,
-                "g_grad_norm": 10}
+                "g_grad_norm": 10, "d_skipped": 11, "g_skipped": 12}
 
 
 class Config(C.Structure):

@@ -62,13 +62,17 @@ struct WgradArgs {
 // launch is bracketed by HIP events on its own stream and tagged with its algorithmic FLOPs.
 struct Prof {
     struct Rec { int id; double flops, bytes; hipEvent_t e0, e1; };   // algorithmic FLOPs and HBM bytes (operands read once + result written once)
-    static constexpr int NID = 8;
+    static constexpr int NID = 9;
     std::vector<Rec> recs;
     static const char* name(int id);
     void begin(int id, double flops, double bytes, hipStream_t st);
     void clear();
 };
 extern Prof* g_prof;
+
+// experiment switch: an integer read ONCE from the environment variable `name` (A/B measurements of a kernel choice on the
+// GPU box inside one process image; every switch is removed, or becomes the rule, once measured)
+int exp_knob(const char* name, int dflt);
 
 void launch_gconv(const GConvArgs& a, hipStream_t st);
 // 16-bit operand kernels (gconv16.hip); cfg: 0 = 128x128, 2 = 64x64, 3 = 128x32 tiles; e0 / e1: optional timing events

@@ -17,7 +17,8 @@ struct DevState {
     float grad_mul;                  // grad_scale * clip coefficient
     float grad_norm;                 // pre-clip global L2 norm (after grad_scale)
     float sumsq;                     // scratch of the norm reduction
-    float pad[3];
+    int skip;                        // the pending update is skipped (fp16: the gradient arena holds an inf / NaN)
+    float pad[2];
 };
 
 // ---- RNG (Philox4x32-10, counter = (index, stream, call counter)) --------------------------
@@ -80,6 +81,10 @@ void launch_fc_wgrad(int dt, const void* dy, const float* z, float* dW, float* d
 void launch_bn_train_stats(int dt, const void* y, int64_t R, int C, const float* gamma, const float* beta,
                            float* rmean, float* rvar, int64_t* batches, float* bn, float* partial,
                            int perm_c0, float momentum, float eps, hipStream_t s);
+// the same plus a = relu(y*scale + shift) (a == nullptr: statistics only) in ONE launch for the small layers (a workgroup per
+// float4 channel group over all rows); returns false -- nothing launched -- when the layer is not one of them
+bool launch_bn_train_fused(int dt, const void* y, void* a, int64_t R, int C, const float* gamma, const float* beta, float* rmean,
+                           float* rvar, int64_t* batches, float* bn, int perm_c0, float momentum, float eps, hipStream_t s);
 // a = relu(y*scale + shift)
 void launch_bn_relu(int dt, const void* y, void* a, int64_t R, int C, const float* bn, hipStream_t s);
 // backward through relu(BN(y)): da (in) -> dy (in place); dgamma/dbeta (torch order) written.  The relu mask is
@@ -157,8 +162,11 @@ void launch_sn_combine(const SnTable& t, const float* g0, const float* g1, float
 // reads steps[0], writes steps[i] += 1 for every tensor, derives the Adam scalars; with
 // clip_max_norm > 0 also needs the gradient norm (launch_grad_sumsq first)
 void launch_grad_sumsq(const float* g, int64_t n, DevState* st, float* partial, hipStream_t s);
+// check_finite (fp16 chains; needs launch_grad_sumsq first): a non-finite sum of squares marks the update as skipped
+// (DevState::skip: k_adam returns at once, the step counts stay) and writes 1 to *metric_skipped, else 0
 void launch_adam_prepare(DevState* st, float* steps, int ntensors, double lr, double beta1, double beta2,
-                         float grad_scale, float clip_max_norm, float* metric_norm, hipStream_t s);
+                         float grad_scale, float clip_max_norm, float* metric_norm, hipStream_t s,
+                         int check_finite = 0, float* metric_skipped = nullptr);
 void launch_adam(float* p, float* g, float* m, float* v, int64_t n, const DevState* st, double beta1,
                  double beta2, double eps, int write_back_grad, hipStream_t s);
 

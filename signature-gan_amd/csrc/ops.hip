@@ -4,6 +4,7 @@
 // segments) and per-channel reductions are two-stage (per-chunk partials, then a finalize
 // kernel that adds the partials in chunk order), so results are bitwise reproducible.
 #include "ops.h"
+#include "gconv.h"   // exp_knob
 #include "rng.h"
 
 namespace siggan {
@@ -266,6 +267,117 @@ struct FBnBwd {   // relu mask re-derived from y (a > 0 <=> fma(y, scale, shift)
 // =========================================================================================
 // BatchNorm
 // =========================================================================================
+// ---- small layers: ONE workgroup owns a float4 channel group over ALL R rows, so statistics, finalize and apply are one
+// launch (no partial rows, no finalize kernel): the Generator's 8x8 / 16x16 blocks, whose three-launch chains are pure launch
+// latency.  The second pass re-reads the (L2-resident) tensor.  1024 threads; sums: thread-strided, then waves, then LDS.
+__device__ __forceinline__ void block_sum8(f32x4& a, f32x4& b, f32x4 (*sh)[2]) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] += __shfl_xor(a[k], o); b[k] += __shfl_xor(b[k], o); }
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh[w][0] = a; sh[w][1] = b; }
+    __syncthreads();
+    if (w == 0) {                                   // the 16 wave sums: one more shuffle tree in wave 0
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 x = lane < 16 ? sh[lane][0] : z, y = lane < 16 ? sh[lane][1] : z;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x[k] += __shfl_xor(x[k], o); y[k] += __shfl_xor(y[k], o); }
+        }
+        if (lane == 0) { sh[0][0] = x; sh[0][1] = y; }
+    }
+    __syncthreads();
+    a = sh[0][0]; b = sh[0][1];
+}
+template <class T>
+__global__ __launch_bounds__(1024) void k_bn_fwd_small(const T* __restrict__ y, T* __restrict__ a, int R, int C,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ rmean, float* __restrict__ rvar,
+                                                       int64_t* __restrict__ batches, float* __restrict__ bn, float momentum,
+                                                       float eps) {
+    __shared__ f32x4 sh[16][2];
+    const int c0 = blockIdx.x * 4;
+    const T* col = y + c0;
+    const f32x4 p = ld4<T>(col);                                      // shift: the first row (robust single-pass variance)
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll 2
+    for (int r = threadIdx.x; r < R; r += 1024) {
+        const f32x4 d = ld4<T>(col + (size_t)r * C) - p;
+        s0 += d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s1[k] = fmaf(d[k], d[k], s1[k]);
+    }
+    block_sum8(s0, s1, sh);
+    const float invR = 1.0f / (float)R;
+    f32x4 sc, sf;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float d = s0[k] * invR, mean = p[k] + d;
+        float var = s1[k] * invR - d * d;
+        var = var > 0.f ? var : 0.f;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        sc[k] = gamma[c0 + k] * rstd; sf[k] = beta[c0 + k] - mean * sc[k];
+        if (threadIdx.x == 0) {
+            const int c = c0 + k;
+            bn[c] = sc[k]; bn[C + c] = sf[k]; bn[2 * C + c] = mean; bn[3 * C + c] = rstd;
+            const float unb = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+            rmean[c] = momentum * mean + (1.0f - momentum) * rmean[c];
+            rvar[c] = momentum * unb + (1.0f - momentum) * rvar[c];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && batches) batches[0] += 1;
+    if (!a) return;
+#pragma unroll 2
+    for (int r = threadIdx.x; r < R; r += 1024) {
+        const f32x4 v = ld4<T>(col + (size_t)r * C);
+        st4<T>(a + c0 + (size_t)r * C, f32x4{fmaxf(fmaf(v[0], sc[0], sf[0]), 0.f), fmaxf(fmaf(v[1], sc[1], sf[1]), 0.f),
+                                            fmaxf(fmaf(v[2], sc[2], sf[2]), 0.f), fmaxf(fmaf(v[3], sc[3], sf[3]), 0.f)});
+    }
+}
+template <class T>
+__global__ __launch_bounds__(1024) void k_bn_bwd_small(T* __restrict__ da, const T* __restrict__ y, int R, int C,
+                                                       float* __restrict__ bn, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta) {
+    __shared__ f32x4 sh[16][2];
+    const int c0 = blockIdx.x * 4;
+    const f32x4 sc = ld4<float>(bn + c0), sf = ld4<float>(bn + C + c0), mu = ld4<float>(bn + 2 * C + c0), rs = ld4<float>(bn + 3 * C + c0);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll 4
+    for (int r = threadIdx.x; r < R; r += 1024) {
+        const f32x4 g = ld4<T>(da + c0 + (size_t)r * C), v = ld4<T>(y + c0 + (size_t)r * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = fmaf(v[k], sc[k], sf[k]) > 0.f ? g[k] : 0.f;
+            s0[k] += d;
+            s1[k] = fmaf(d, (v[k] - mu[k]) * rs[k], s1[k]);
+        }
+    }
+    block_sum8(s0, s1, sh);
+    const float invR = 1.0f / (float)R;
+    const f32x4 c1 = s0 * invR, c2 = s1 * invR;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dbeta[c0 + k] = s0[k]; dgamma[c0 + k] = s1[k]; bn[4 * C + c0 + k] = c1[k]; bn[5 * C + c0 + k] = c2[k]; }
+    }
+#pragma unroll 4
+    for (int r = threadIdx.x; r < R; r += 1024) {
+        const f32x4 g = ld4<T>(da + c0 + (size_t)r * C), v = ld4<T>(y + c0 + (size_t)r * C);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = sc[k] * ((fmaf(v[k], sc[k], sf[k]) > 0.f ? g[k] : 0.f) - c1[k] - (v[k] - mu[k]) * rs[k] * c2[k]);
+        st4<T>(da + c0 + (size_t)r * C, o);
+    }
+}
+// the one-launch kernels cover a layer when every workgroup's column is small enough to stay in L2 between its two passes
+// and there are enough columns to occupy a few CUs
+static bool bn_small(int64_t R, int C, int perm_c0) {
+    return perm_c0 == 0 && C >= 64 && (C & 3) == 0 && R <= 16384 && exp_knob("SIGGAN_X_BN_SMALL", 1) != 0;
+}
+
 template <int W, class T>
 __global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
                                const T* __restrict__ y, const float* __restrict__ gamma,
@@ -290,6 +402,13 @@ __global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__
     const float unb = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
     rmean[t] = momentum * mean + (1.0f - momentum) * rmean[t];
     rvar[t] = momentum * unb + (1.0f - momentum) * rvar[t];
+}
+bool launch_bn_train_fused(int dt, const void* yv, void* av, int64_t R, int C, const float* gamma, const float* beta, float* rmean,
+                           float* rvar, int64_t* batches, float* bn, int perm_c0, float momentum, float eps, hipStream_t s) {
+    if (!bn_small(R, C, perm_c0)) return false;
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_bn_fwd_small<T>, dim3(C / 4), dim3(1024), 0, s, (const T*)yv, (T*)av, (int)R, C, gamma, beta,
+                                                rmean, rvar, batches, bn, momentum, eps));
+    return true;
 }
 void launch_bn_train_stats(int dt, const void* yv, int64_t R, int C, const float* gamma, const float* beta, float* rmean,
                            float* rvar, int64_t* batches, float* bn, float* partial, int perm_c0, float momentum,
@@ -359,6 +478,11 @@ __global__ void k_bn_bwd_apply(T* __restrict__ da, const T* __restrict__ y, int6
 }
 void launch_bn_bwd(int dt, void* dav, const void* yv, int64_t R, int C, float* bn, float* partial,
                    float* dgamma, float* dbeta, int perm_c0, hipStream_t s) {
+    if (bn_small(R, C, perm_c0)) {
+        SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_bn_bwd_small<T>, dim3(C / 4), dim3(1024), 0, s, (T*)dav, (const T*)yv, (int)R, C, bn,
+                                                    dgamma, dbeta));
+        return;
+    }
     const ColPlan pl = col_plan(R, C);
     float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
     const int64_t n4 = R * C / 4;
@@ -629,12 +753,12 @@ __device__ __forceinline__ f4v final_dact(const float (&d)[RY + 2][3], const f4v
 //     with act = relu(fma(y, scale, shift)) re-derived the same way (the activation tensor is not materialised in training).
 // A block walks 8-row strips (grid-stride), folds the 32 pixel lanes (shuffles inside a wave, LDS across the 4 waves, fixed
 // order) and writes one partial row per output family; k_bn_bwd_fin / k_rows_sum add the rows.
-template <class T>
+template <class T, int RY>
 __global__ __launch_bounds__(256) void k_final_bwd_reduce(const float* __restrict__ dpre, const float* __restrict__ W,
                                                           const T* __restrict__ y, const float* __restrict__ bn,
                                                           float* __restrict__ p0, float* __restrict__ p1,
                                                           float* __restrict__ pw, int S, int nstrips) {
-    constexpr int RY = 8, C = 32;
+    constexpr int C = 32;
     __shared__ f4v sh[2][4][8];
     __shared__ float shw[4][8][37];
     const int c4 = threadIdx.x & 7, wave = threadIdx.x >> 6;
@@ -756,13 +880,20 @@ __global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ par
     if (threadIdx.x >= 64 || j >= width) return;
     if (j < n0) o0[j] = s; else o1[j - n0] = s;
 }
-static int final_reduce_rows(int B, int S) { const int n8 = B * (S / 8) * (S / 32); return n8 < 1024 ? n8 : 1024; }
+// rows per strip of k_final_bwd_reduce: 8 (256 VGPRs) or 4 (188)
+static int final_ry() { return exp_knob("SIGGAN_X_FINAL_RY", 4) == 8 ? 8 : 4; }
+static int final_reduce_rows(int B, int S) {
+    const int cap = exp_knob("SIGGAN_X_FINAL_ROWS", 1024);
+    const int n = B * (S / final_ry()) * (S / 32); return n < cap ? n : cap;
+}
 void launch_final_bwd_reduce(int dt, const float* dpre, const float* W, const void* y, int B, int S, int C, const float* bn,
                              float* partial, float* partial_w, hipStream_t s) {
-    const int nstrips8 = B * (S / 8) * (S / 32), nch = final_reduce_rows(B, S);
+    const int ry = final_ry(), nstrips = B * (S / ry) * (S / 32), nch = final_reduce_rows(B, S);
     float* p0 = partial; float* p1 = partial + (size_t)nch * C;
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_bwd_reduce<T>, dim3(nch), dim3(256), 0, s, dpre, W, (const T*)y, bn, p0, p1,
-                                                partial_w, S, nstrips8));
+    SIGGAN_DT_SWITCH(dt, T, {
+        if (ry == 8) hipLaunchKernelGGL((k_final_bwd_reduce<T, 8>), dim3(nch), dim3(256), 0, s, dpre, W, (const T*)y, bn, p0, p1, partial_w, S, nstrips);
+        else hipLaunchKernelGGL((k_final_bwd_reduce<T, 4>), dim3(nch), dim3(256), 0, s, dpre, W, (const T*)y, bn, p0, p1, partial_w, S, nstrips);
+    });
 }
 void launch_final_wgrad_fin(const float* partial_w, float* dW, float* db, int B, int S, int C, hipStream_t s) {
     hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 64)), dim3(1024), 0, s, partial_w, final_reduce_rows(B, S), C * 9 + 1, dW, C * 9, db);
@@ -915,10 +1046,10 @@ void launch_conv1_wgrad(int dt, const void* dv, const float* x0, int n0, const f
 // blocks: block (a, b) = image pixels (2a..2a+1, 2b..2b+1) needs dv rows a-1..a+1, cols b-1..b+1 and
 // every tap exactly once (ih = 2a: kh 1 -> oh a, kh 3 -> oh a-1; ih = 2a+1: kh 0 -> oh a+1, kh 2 -> oh a).
 // 16 channel lanes x 16 columns per block, RA block rows per thread (sliding 3-row window).
-template <class T>
+template <class T, int RA>
 __global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const T* __restrict__ dv, const float* __restrict__ W,
                                                           const float* __restrict__ img, float* __restrict__ dpre, int S) {
-    constexpr int RA = 4, C = 64;
+    constexpr int C = 64;
     const int Ho = S >> 1, nbb = Ho >> 4, nba = Ho / RA;
     const int q = threadIdx.x & 15, bl = threadIdx.x >> 4;
     int bid = blockIdx.x;
@@ -977,7 +1108,12 @@ void launch_conv1_dgrad_tanh(int dt, const void* dv, const float* W, const float
                              hipStream_t s) {
     (void)C;
     const int Ho = S / 2;
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_conv1_dgrad_tanh<T>, dim3(B * (Ho / 4) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, W, img, dpre, S));
+    SIGGAN_DT_SWITCH(dt, T, {
+        if (exp_knob("SIGGAN_X_C1D_RA", 4) == 2)
+            hipLaunchKernelGGL((k_conv1_dgrad_tanh<T, 2>), dim3(B * (Ho / 2) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, W, img, dpre, S);
+        else
+            hipLaunchKernelGGL((k_conv1_dgrad_tanh<T, 4>), dim3(B * (Ho / 4) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, W, img, dpre, S);
+    });
 }
 
 // =========================================================================================
@@ -1201,13 +1337,19 @@ void launch_grad_sumsq(const float* g, int64_t n, DevState* st, float* partial, 
 }
 
 __global__ void k_adam_prepare(DevState* st, float* __restrict__ steps, int ntensors, double lr, double beta1, double beta2,
-                               float grad_scale, float clip_max_norm, float* __restrict__ metric_norm) {
+                               float grad_scale, float clip_max_norm, float* __restrict__ metric_norm, int check_finite,
+                               float* __restrict__ metric_skipped) {
+    // fp16 chains carry a static gradient scale: an activation gradient that overflowed arrives here as inf / NaN in the sum
+    // of squares -- the update is skipped (parameters, moments, step counts untouched) instead of poisoning the fp32 masters
+    const bool skip = check_finite && !isfinite(st->sumsq);
     // torch.optim.Adam: step += 1; bias corrections as Python doubles (1 - beta**step)
     const float t = steps[0] + 1.0f;
     __syncthreads();
-    for (int i = threadIdx.x; i < ntensors; i += blockDim.x) steps[i] = t;
+    if (!skip) for (int i = threadIdx.x; i < ntensors; i += blockDim.x) steps[i] = t;
     if (threadIdx.x != 0) return;
     st->rng_ctr += 1;                       // every optimiser update starts a new RNG epoch (z, dropout tables)
+    st->skip = skip ? 1 : 0;
+    if (metric_skipped) *metric_skipped = skip ? 1.0f : 0.0f;
     const double bc1 = 1.0 - pow(beta1, (double)t);
     const double bc2 = 1.0 - pow(beta2, (double)t);
     st->step_size = (float)(lr / bc1);
@@ -1223,9 +1365,9 @@ __global__ void k_adam_prepare(DevState* st, float* __restrict__ steps, int nten
     st->grad_mul = mul;
 }
 void launch_adam_prepare(DevState* st, float* steps, int ntensors, double lr, double beta1, double beta2, float grad_scale,
-                         float clip_max_norm, float* metric_norm, hipStream_t s) {
+                         float clip_max_norm, float* metric_norm, hipStream_t s, int check_finite, float* metric_skipped) {
     hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, s, st, steps, ntensors, lr, beta1, beta2, grad_scale,
-                       clip_max_norm, metric_norm);
+                       clip_max_norm, metric_norm, check_finite, metric_skipped);
 }
 
 __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
@@ -1234,6 +1376,7 @@ __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __
                                               int tail, const DevState* __restrict__ st, float w1, float beta2,
                                               float w2, float eps, int wb) {
     // w1 = (float)(1 - beta1), w2 = (float)(1 - beta2): formed in double on the host, as torch does
+    if (st->skip) return;                   // (uniform: k_adam_prepare found a non-finite fp16 gradient)
     const float mul = st->grad_mul, ss = -st->step_size, bc2 = st->bc2_sqrt;
     auto upd = [&](float& pp, float& gg, float& mm, float& vv) {
         const float gr = gg * mul;

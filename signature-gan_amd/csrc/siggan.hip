@@ -171,6 +171,7 @@ struct siggan_ctx {
     // data-parallel communicator (siggan_comm_init): world 1 = none
     ncclComm_t comm; int comm_rank, comm_world; int comm_err;
     int staged_B;        // batch of a real batch staged for the NEXT D step by siggan_stage_real (0: none)
+    const float* staged_src;   // where that batch lies: the library's copy (real_next), or the caller's own tensor
     int dreal_B;         // batch whose D(real) forward siggan_g_grads already enqueued on lane c (0: none)
     int zg_stash;        // batch of an explicit G-step z handed to siggan_step_begin when the forward was not pipelined
     int g_fwd_pending;   // batch of a Generator training forward already enqueued by siggan_step_begin (0: none)
@@ -356,7 +357,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->s_c, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_gfwd, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_dreal, hipEventDisableTiming));
-    c->staged_B = c->dreal_B = 0;
+    c->staged_B = c->dreal_B = 0; c->staged_src = nullptr;
     c->dreal_orphan = false; c->lane_err = hipSuccess;
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1; c->comm_err = 0;
     c->g_fwd_pending = 0;
@@ -621,12 +622,16 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
             a.out = c->g_y[l]; a.epi = EPI_RAW;
             launch_gconv(a, s);
             const int64_t R = (int64_t)B * 4 * Hi * Hi;
-            launch_bn_train_stats(c->dt, c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
-                                  c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
-                                  BN_MOMENTUM, BN_EPS, s);
             // the LAST block's activation has two readers, the final conv here and its weight gradient in the backward
             // pass: both re-derive it from y and this table, so it is never written (33.5 MB each way at batch 64)
-            if (l < c->Lg) launch_bn_relu(c->dt, c->g_y[l], c->g_a[l], R, C, c->g_bn[l], s);
+            void* const act = l < c->Lg ? c->g_a[l] : nullptr;
+            if (!launch_bn_train_fused(c->dt, c->g_y[l], act, R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
+                                       c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], 0, BN_MOMENTUM, BN_EPS, s)) {
+                launch_bn_train_stats(c->dt, c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
+                                      c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
+                                      BN_MOMENTUM, BN_EPS, s);
+                if (act) launch_bn_relu(c->dt, c->g_y[l], act, R, C, c->g_bn[l], s);
+            }
         } else {
             a.out = c->g_a[l]; a.epi = EPI_AFFINE_RELU; a.scale = c->g_bne[l]; a.shift = c->g_bne[l] + C;
             launch_gconv(a, s);
@@ -680,22 +685,32 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
     const float* const w1 = c->sn ? c->d_w1s : DP(c, di_w(1));
     // sigmoid + BCE: losses / means into the metrics, d(logit) for the classifier's weight gradient -- on lane b; the
     // chain below recomputes d(logit) from the logits and does not wait for it
-    L.fork(L.b);
-    launch_bce(c->logits + r0, Bd, bce.n0, bce.y0, bce.y1, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, L.b, c->gscale);
+    // (experiment switches, see DESIGN 4: every fork is an event record on the main lane, and the kernel behind it starts
+    // ~6 us late; a join whose event completes just before it is waited for costs ~15 us)
+    const int x_dbwd = want_wgrad ? exp_knob("SIGGAN_X_DBWD", 0) : 0;          // D step: 1 = weight gradients on the main lane; 2 = no side lane at all
+    const bool bce_main = (!want_wgrad && exp_knob("SIGGAN_X_GBCE_MAIN", 0)) || x_dbwd == 2;
+    hipStream_t const sb = bce_main ? L.m : L.b;
+    hipStream_t const sa = x_dbwd >= 1 ? L.m : L.a;
+    if (sb != L.m) L.fork(L.b);
+    launch_bce(c->logits + r0, Bd, bce.n0, bce.y0, bce.y1, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, sb, c->gscale);
     launch_cls_bwd(c->dt, c->logits + r0, bce.n0, bce.y0, bce.y1, c->wcp, act(Ld), nz(Ld), slope, dvp(Ld), Bd,
                    c->dC[Ld], L.m, c->gscale);
     if (want_wgrad)
-        launch_cls_wgrad(c->dt, c->dlogit + r0, act(Ld), G_(di_cls_w(c)), G_(di_cls_b(c)), Bd, c->dC[Ld], L.b);
+        launch_cls_wgrad(c->dt, c->dlogit + r0, act(Ld), G_(di_cls_w(c)), G_(di_cls_b(c)), Bd, c->dC[Ld], sb);
+    auto wgrad_of = [&](int l) {
+        const int Ho = c->S >> l, Co = c->dC[l], Ci = c->dC[l - 1];
+        WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
+        w.S = dvp(l); w.L = act(l - 1); w.slab = c->slab; w.dw = G_(di_w(l)); w.B = Bd; w.Cs = Co; w.Cl = Ci;
+        w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
+        w.db = G_(di_b(l));                              // bias gradient = column sums of d(pre-activation): rides in the same kernel
+        const int max_splits = (int)(c->slab_floats / ((int64_t)Co * (16 * Ci + 1)));
+        launch_wgrad(w, max_splits, sa);
+    };
     for (int l = Ld; l >= 2; --l) {
         const int Ho = c->S >> l, Hi = 2 * Ho, Co = c->dC[l], Ci = c->dC[l - 1];
-        if (want_wgrad) {
+        if (want_wgrad && x_dbwd == 0) {
             L.fork(L.a);                                   // d_dv[l] is complete on m here
-            WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
-            w.S = dvp(l); w.L = act(l - 1); w.slab = c->slab; w.dw = G_(di_w(l)); w.B = Bd; w.Cs = Co; w.Cl = Ci;
-            w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
-            w.db = G_(di_b(l));                              // bias gradient = column sums of d(pre-activation): rides in the same kernel
-            const int max_splits = (int)(c->slab_floats / ((int64_t)Co * (16 * Ci + 1)));
-            launch_wgrad(w, max_splits, L.a);
+            wgrad_of(l);
         }
         // input gradient ("up" form): contract Cout, produce Cin at (Hi x Hi); fused leaky'/dropout of block l-1
         GConvArgs a = gconv_args(c);
@@ -704,13 +719,14 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
         a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 1; a.M = Bd * Ho * Ho;
         a.epi = EPI_LRELU_BWD; a.aref = act(l - 1); a.noise = nz(l - 1); a.slope = slope;
         launch_gconv(a, L.m);
+        if (want_wgrad && x_dbwd >= 1) wgrad_of(l);        // behind the input gradient on the same lane (the slab is reused in order)
     }
     if (want_wgrad) {
-        L.fork(L.b);
-        launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
-        L.join(L.a);
+        if (sb != L.m) L.fork(L.b);
+        launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], sb);
+        if (sa != L.m) L.join(L.a);
     }
-    L.join(L.b);
+    if (sb != L.m) L.join(L.b);
     if (want_dimage)
         launch_conv1_dgrad_tanh(c->dt, dvp(1), w1, x0, c->dpre, Bd, c->S, c->dC[1], L.m);
 }
@@ -719,39 +735,53 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
 // BatchNorm backward and the input-gradient chain; lane a: the weight gradients.
 static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     const int Lg = c->Lg, S = c->S;
+    // experiment switch: 0 = one fork per block (each weight gradient starts as soon as its dy exists); 1 = one fork per TWO
+    // blocks; 2 = weight gradients on the main lane (no side lane a); 3 = ONE fork, after the whole chain
+    const int x_gfork = exp_knob("SIGGAN_X_GFORK", 0);
+    const bool fin_main = exp_knob("SIGGAN_X_GFIN_MAIN", 0) != 0;    // the final conv's gradient row sums on the main lane (no lane b)
+    int pending[MAXL + 1], npend = 0;
+    auto wgrad_of = [&](int l, hipStream_t st) {
+        const int Hi = 4 << (l - 1), Ci = c->gC[l - 1], Co = c->gC[l];
+        // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
+        WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
+        w.S = c->g_a[l - 1]; w.L = c->g_da[l]; w.slab = c->slab; w.dw = GG(c, gi_up_w(l)); w.B = B; w.Cs = Ci; w.Cl = Co;
+        w.lgHs = ilog2i(Hi); w.lgWs = w.lgHs; w.lgCl = ilog2i(Co); w.K = B * Hi * Hi;
+        const int max_splits = (int)(c->slab_floats / ((int64_t)Ci * (16 * Co + 1)));
+        launch_wgrad(w, max_splits, st);
+    };
+    auto flush = [&]() { if (npend) { L.fork(L.a); for (int i = 0; i < npend; ++i) wgrad_of(pending[i], L.a); npend = 0; } };
     for (int l = Lg; l >= 1; --l) {
         const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
         const int64_t R = (int64_t)B * Ho * Ho;
         if (l == Lg) {   // final conv's input-gradient folded into this block's BatchNorm backward; its weight gradient rides in
                          // the same pass over y (the row sums of that gradient go to lane b)
             launch_final_bwd_reduce(c->dt, c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b, L.m);
-            L.fork(L.b);
-            launch_final_wgrad_fin(c->partial_b, GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), B, S, Co, L.b);
+            if (!fin_main) L.fork(L.b);
+            launch_final_wgrad_fin(c->partial_b, GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), B, S, Co, fin_main ? L.m : L.b);
             launch_final_bn_bwd_apply(c->dt, c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
                                       GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
         } else
             launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m);
-        L.fork(L.a);                                       // dy[l] is complete on m here
-        // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
-        WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
-        w.S = c->g_a[l - 1]; w.L = c->g_da[l]; w.slab = c->slab; w.dw = GG(c, gi_up_w(l)); w.B = B; w.Cs = Ci; w.Cl = Co;
-        w.lgHs = ilog2i(Hi); w.lgWs = w.lgHs; w.lgCl = ilog2i(Co); w.K = B * Hi * Hi;
-        const int max_splits = (int)(c->slab_floats / ((int64_t)Ci * (16 * Co + 1)));
-        launch_wgrad(w, max_splits, L.a);
+        // dy[l] is complete on m here
+        pending[npend++] = l;
+        if (x_gfork == 0 || (x_gfork == 1 && ((Lg - l) & 1) == 1)) flush();
         // input gradient ("down" form): out = Cin at Hi, contract Cout over 16 taps
         GConvArgs a = gconv_args(c);
         a.in = c->g_da[l]; a.wp = c->g_dn[l]; a.out = c->g_da[l - 1];
         a.B = B; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
         launch_gconv(a, L.m);
+        if (x_gfork == 2) { for (int i = 0; i < npend; ++i) wgrad_of(pending[i], L.m); npend = 0; }
     }
+    if (x_gfork != 2) flush();
     if (!(c->fc_fused && launch_fc_bwd_fused(c->dt, c->g_da[0], c->fc_y, z, c->g_bn[0], GG(c, gi_fc_w()), GG(c, gi_fc_b()),
                                              GG(c, gi_bn0_w()), GG(c, gi_bn0_b()), B, c->latent, c->gC[0], L.m))) {
         launch_bn_bwd(c->dt, c->g_da[0], c->fc_y, B, c->F, c->g_bn[0], c->partial, GG(c, gi_bn0_w()), GG(c, gi_bn0_b()),
                       c->gC[0], L.m);
         launch_fc_wgrad(c->dt, c->g_da[0], z, GG(c, gi_fc_w()), GG(c, gi_fc_b()), B, c->latent, c->gC[0], L.m);
     }
-    L.join(L.a); L.join(L.b);
+    if (x_gfork != 2) L.join(L.a);
+    if (!fin_main) L.join(L.b);
 }
 
 // dropout multiplier tables of passes [p0, p1) (pass 0 = rows [0,B) = D(real), pass 1 = rows [B,2B) = D(fake)).
@@ -799,7 +829,7 @@ static void phase_d_grads_sn(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const bool drop = c->cfg.dropout > 0.f;
     repack(c, L.m, L.m, k.g_dirty != 0, false);
     if (k.pre_real)
-        L.note(hipMemcpyAsync(c->real_stage, c->real_next, (size_t)B * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, L.m));
+        L.note(hipMemcpyAsync(c->real_stage, c->staged_src, (size_t)B * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, L.m));
     if (drop) make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, 0, 2, L.m);
     const float* fake = c->img;
     if (k.variant == SIGGAN_STEP_ABLATION) {
@@ -830,7 +860,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     L.fork(L.a);                                                     // lane a: D's packs, dropout tables, D(real)
     repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
     if (k.pre_real)      // staged batch -> this step's real batch (the D backward reads it again)
-        L.note(hipMemcpyAsync(c->real_stage, c->real_next, (size_t)B * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, L.a));
+        L.note(hipMemcpyAsync(c->real_stage, c->staged_src, (size_t)B * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, L.a));
     if (drop) make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, k.pre_real == 2 ? 1 : 0, 2, L.a);
     // D(real) beside the Generator (train...py:309) -- unless the previous siggan_g_grads already ran it
     // (siggan_stage_real) beside its Generator backward; then bce only has to wait for that lane
@@ -903,7 +933,7 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         const bool drop = c->cfg.dropout > 0.f;
         L.fork(c->s_c);
         if (drop) make_noise(c, nullptr, B, 0, 1, c->s_c, 1);
-        d_forward_rows(c, c->real_next, 0, B, drop, c->s_c, c->slab_k2);
+        d_forward_rows(c, c->staged_src, 0, B, drop, c->s_c, c->slab_k2);
         L.record(c->ev_dreal, c->s_c);
     }
     g_backward_pass(c, L, zg, B);
@@ -934,9 +964,11 @@ static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         if (e != NCCL_SUCCESS) { c->comm_err = e; return; }
         gs *= 1.0f / (float)c->comm_world;
     }
-    if (clip) launch_grad_sumsq(g, n, c->dev, c->partial, L.m);
+    const bool guard = c->dt == DT_F16;                              // static gradient scale: skip the update on an overflow
+    if (clip || guard) launch_grad_sumsq(g, n, c->dev, c->partial, L.m);
     launch_adam_prepare(c->dev, steps, nt, k.lr, k.beta1, k.beta2, gs, k.clip,
-                        k.mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), L.m);
+                        k.mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), L.m, guard ? 1 : 0,
+                        k.mt + (which == 0 ? SIGGAN_M_G_SKIPPED : SIGGAN_M_D_SKIPPED));
     launch_adam(p, g, m, v, n, c->dev, k.beta1, k.beta2, k.eps, (clip || gs != 1.0f) ? 1 : 0, L.m);
 }
 
@@ -1118,7 +1150,12 @@ extern "C" int siggan_stage_real(siggan_ctx* c, const float* real_dev, int32_t b
     if (!real_dev) return fail(SIGGAN_E_INVALID, "null real batch");
     drop_dreal(c);                     // an early D(real) forward of a previously staged batch still reads real_next
     if ((rc = settle(c, (hipStream_t)stream))) return rc;
-    HIPCHK(hipMemcpyAsync(c->real_next, real_dev, (size_t)batch * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (exp_knob("SIGGAN_X_STAGE_PTR", 0)) {
+        c->staged_src = real_dev;      // borrowed: the caller keeps the tensor alive and unmodified until the next D step has taken it
+    } else {
+        HIPCHK(hipMemcpyAsync(c->real_next, real_dev, (size_t)batch * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        c->staged_src = c->real_next;
+    }
     c->staged_B = batch;
     return SIGGAN_OK;
 }

@@ -220,7 +220,9 @@ class GANTrainer:
                 "discriminator_state_dict": snap(self.model.discriminator.state_dict()),
                 "g_optimizer_state_dict": opt_sd(self.model.g_optimizer),
                 "d_optimizer_state_dict": opt_sd(self.model.d_optimizer),
-                "config": self.config.to_dict(), "fixed_noise": self.fixed_noise.cpu(), "best_g_loss": self.best_g_loss}
+                "config": self.config.to_dict(), "fixed_noise": self.fixed_noise.cpu(), "best_g_loss": self.best_g_loss,
+                # extra key (the reference's loaders ignore it): where the library's z / dropout stream stands
+                "engine_rng_state": list(self.model.engine.rng_state())}
 
     def _save_checkpoint(self, epoch: int, is_best: bool = False) -> Path:
         ck = self._checkpoint_dict(epoch)
@@ -249,7 +251,10 @@ class GANTrainer:
         # a resumed run must not replay the z / dropout draws of steps 0..N: position the library RNG behind them
         # (one tick per optimiser update = n_critic + 1 per batch)
         eng = self.model.engine
-        eng.seed(eng._seed, offset=(int(getattr(self.config, "n_critic", 1)) + 1) * int(self.global_step))
+        if "engine_rng_state" in ck:            # written by this trainer / VanillaGAN.save: the exact position
+            eng.seed(int(ck["engine_rng_state"][0]), offset=int(ck["engine_rng_state"][1]))
+        else:                                   # a reference-written checkpoint: the estimate
+            eng.seed(eng._seed, offset=(int(getattr(self.config, "n_critic", 1)) + 1) * int(self.global_step))
         self.best_g_loss = ck.get("best_g_loss", float("inf"))
         if "fixed_noise" in ck:
             self.fixed_noise = ck["fixed_noise"].to(self.model.device)

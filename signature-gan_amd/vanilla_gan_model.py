@@ -186,7 +186,9 @@ class VanillaGAN(nn.Module):
               "generator_state_dict": self._snapshot(self.generator.state_dict()),
               "discriminator_state_dict": self._snapshot(self.discriminator.state_dict()),
               "current_epoch": self.current_epoch, "global_step": self.global_step,
-              "saved_at": datetime.now().isoformat()}
+              "saved_at": datetime.now().isoformat(),
+              # extra key (the reference's loaders ignore it): where the library's z / dropout stream stands
+              "engine_rng_state": list(self.engine.rng_state())}
         if save_optimizer:
             for key, opt in (("g_optimizer_state_dict", self.g_optimizer), ("d_optimizer_state_dict", self.d_optimizer)):
                 sd = opt.state_dict()
@@ -211,8 +213,12 @@ class VanillaGAN(nn.Module):
         self.discriminator.load_state_dict(ck["discriminator_state_dict"])
         self.current_epoch = ck.get("current_epoch", 0)
         self.global_step = ck.get("global_step", 0)
-        # continue the z / dropout stream behind the steps already taken (the counter ticks once per optimiser update)
-        self.engine.seed(self.engine._seed, offset=2 * int(self.global_step))
+        # continue the z / dropout stream where the saved run stood; a checkpoint without the key (written by the reference)
+        # gets the estimate "two optimiser updates per global step" (exact for train_step with n_critic = 1)
+        if "engine_rng_state" in ck:
+            self.engine.seed(int(ck["engine_rng_state"][0]), offset=int(ck["engine_rng_state"][1]))
+        else:
+            self.engine.seed(self.engine._seed, offset=2 * int(self.global_step))
         if load_optimizer and "g_optimizer_state_dict" in ck:
             self.g_optimizer.load_state_dict(ck["g_optimizer_state_dict"])
             self.d_optimizer.load_state_dict(ck["d_optimizer_state_dict"])

@@ -75,7 +75,8 @@ def _grad_errs(views, ref):
     per = {k: v for k, v in per.items() if float(ref[k].double().norm()) > 1e-4 * tot}
     flat_got = torch.cat([views[k].cpu().reshape(-1) for k in views])
     flat_ref = torch.cat([ref[k].reshape(-1) for k in views])
-    return max(per.values()), _rel_l2(flat_got, flat_ref)
+    worst = max(per, key=per.get)
+    return per[worst], _rel_l2(flat_got, flat_ref), worst, {k: round(v, 5) for k, v in per.items()}
 
 
 def _metric_err(got, ref, keys):
@@ -116,7 +117,9 @@ def test_narrow_steps(dtype, size, latent, batch):
         if qq:
             row["d_sign_frac"], row["d_sign_dist"] = _sign_stats(signs, rec, keep=masks)
         row[f"d_metric_vs_{tag}"] = _metric_err(met, o_met, dkeys)
-        row[f"d_grad_t_vs_{tag}"], row[f"d_grad_all_vs_{tag}"] = _grad_errs(eng.views("d", "grads"), o_grads)
+        row[f"d_grad_t_vs_{tag}"], row[f"d_grad_all_vs_{tag}"], row[f"d_grad_worst_tensor_vs_{tag}"], per = _grad_errs(eng.views("d", "grads"), o_grads)
+        if not qq:
+            row["d_grad_per_tensor_vs_fp32"] = per
         row[f"d_exp_avg_vs_{tag}"] = max(_rel_l2(v.cpu(), d_opt.m[k]) for k, v in eng.views("d", "exp_avg").items())
     eng.close()
 
@@ -131,7 +134,9 @@ def test_narrow_steps(dtype, size, latent, batch):
         if qq:
             row["g_sign_frac"], row["g_sign_dist"] = _sign_stats(signs, rec)
         row[f"g_metric_vs_{tag}"] = _metric_err(met, o_met, ("g_loss", "g_fake_mean"))
-        row[f"g_grad_t_vs_{tag}"], row[f"g_grad_all_vs_{tag}"] = _grad_errs(eng.views("g", "grads"), o_grads)
+        row[f"g_grad_t_vs_{tag}"], row[f"g_grad_all_vs_{tag}"], row[f"g_grad_worst_tensor_vs_{tag}"], per = _grad_errs(eng.views("g", "grads"), o_grads)
+        if not qq:
+            row["g_grad_per_tensor_vs_fp32"] = per
         bn = eng.bn_views()
         row[f"bn_vs_{tag}"] = max(float((t.float().cpu() - g_sd[k].float()).abs().max() / (g_sd[k].float().abs().max() + 1e-30))
                                   for k, t in bn.items() if "num_batches" not in k)
@@ -194,3 +199,32 @@ def test_narrow_training_runs_and_matches_modes(dtype):
     for a, b in zip(ref_m, f32_m):
         for k in ("d_loss", "g_loss", "d_real_mean", "d_fake_mean"):
             assert np.isfinite(a[k]) and abs(a[k] - b[k]) <= tol * (abs(b[k]) + 0.1), (k, a[k], b[k])
+
+
+def test_f16_overflow_skips_the_update():
+    """fp16 carries a STATIC gradient scale (include/siggan.h, f16_grad_scale): an activation gradient that overflows reaches
+    the weight gradients as inf / NaN.  *_apply must then skip the whole update -- parameters, both moments and the step
+    counts bit-identical -- raise the skipped flag in the metrics, and the following step must run normally again."""
+    from hipcommon import cuda, make_engine
+    from signature_gan_amd import _lib
+    size, latent, batch = 64, 100, 8
+    eng = make_engine(size, latent, batch, warm=True, dtype="f16")
+    real = cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"])))
+    z = cuda(torch.from_numpy(I.gen_z(batch, latent, SEED["z"])))
+    for which, grads, apply, flag in (("d", lambda: eng.d_compute_grads(real, z), eng.d_apply, "d_skipped"),
+                                      ("g", lambda: eng.g_compute_grads(batch, z), eng.g_apply, "g_skipped")):
+        state = lambda: [getattr(eng, f"{which}_{a}").clone() for a in ("params", "exp_avg", "exp_avg_sq", "adam_steps")]
+        grads()
+        before = state()
+        getattr(eng, f"{which}_grads")[1234] = float("inf")
+        apply(clip=0.5)
+        assert float(eng.metrics[_lib.METRIC_INDEX[flag]]) == 1.0
+        for a, b in zip(before, state()):
+            assert torch.equal(a, b), f"{which}: a skipped update changed the state"
+        grads()
+        apply()
+        assert float(eng.metrics[_lib.METRIC_INDEX[flag]]) == 0.0
+        after = state()
+        assert not torch.equal(before[0], after[0]) and float(after[3][0]) == float(before[3][0]) + 1.0
+        assert all(bool(torch.isfinite(t).all()) for t in after)
+    eng.close()
