@@ -142,8 +142,10 @@ int32_t siggan_bn_layers(const siggan_ctx *ctx);
 int64_t siggan_workspace_bytes(const siggan_ctx *ctx);
 
 int siggan_bind(siggan_ctx *ctx, const siggan_storage *st);
-/* tell the library the caller changed parameters / BN buffers behind its back
- * (load_state_dict, manual edits): packed weight copies are rebuilt on next use */
+/* tell the library the caller changed parameters / BN buffers / Adam step tensors behind its back
+ * (load_state_dict, optimizer.load_state_dict, manual edits): packed weight copies are rebuilt on next
+ * use, and the Adam step counts (which the library otherwise tracks on the host, so that an update is ONE
+ * launch) are read back from *_adam_steps before the next *_apply */
 int siggan_params_changed(siggan_ctx *ctx);
 int siggan_seed(siggan_ctx *ctx, uint64_t seed, uint64_t offset);
 /* reads the RNG position back (seed, call counter): a caller that re-creates a context (larger max_batch) or resumes a
@@ -229,9 +231,10 @@ int siggan_d_grads(siggan_ctx *ctx, const float *real_dev, int32_t batch, const 
 int siggan_step_begin(siggan_ctx *ctx, const float *real_dev, int32_t batch, const float *z_dev,
                       const float *masks_dev, const float *zg_dev, const siggan_hyper *hp,
                       float *metrics_dev, void *stream);
-/* Software-pipelining across steps: hands the library the real batch of the NEXT D step (copied, ordered
- * on `stream`; the loop of GANTrainer.train_epoch, train_vanilla_gan_signatures.py:378-405, knows it one
- * iteration early).  Call it after siggan_d_apply and before siggan_g_grads: that siggan_g_grads then
+/* Software-pipelining across steps: hands the library the real batch of the NEXT D step (BORROWED, not
+ * copied: real_dev must stay valid and unmodified until the siggan_d_grads / siggan_step_begin that consumes
+ * it has returned -- that call copies it into the workspace; the loop of GANTrainer.train_epoch,
+ * train_vanilla_gan_signatures.py:378-405, knows the batch one iteration early and its loader keeps it alive).  Call it after siggan_d_apply and before siggan_g_grads: that siggan_g_grads then
  * runs the staged batch's D(real) forward (discriminator weights are final by then) on its own lane beside
  * the Generator backward.  The next siggan_d_grads / siggan_step_begin consumes the staged batch when
  * called with real_dev = NULL (a non-NULL real_dev discards it).  Results are bit-identical to the

@@ -162,6 +162,8 @@ class EngineAdam(torch.optim.Adam):
                     st["exp_avg"].copy_(old[n]["exp_avg"]); st["exp_avg_sq"].copy_(old[n]["exp_avg_sq"])
                 self.state[p] = st
         self._populated_for = eng
+        if any(old.values()):
+            eng.params_changed()                              # step tensors were written: the library re-reads them
         return eng
 
     def state_dict(self):
@@ -186,6 +188,7 @@ class EngineAdam(torch.optim.Adam):
             if not state_dict["state"]:
                 for mine in self.state.values():
                     mine["step"].zero_(); mine["exp_avg"].zero_(); mine["exp_avg_sq"].zero_()
+        eng.params_changed()                                  # the step tensors were written: the library re-reads them (siggan.h)
 
     def zero_grad(self, set_to_none=True):
         eng = self._module._engine

@@ -62,7 +62,7 @@ struct WgradArgs {
 // launch is bracketed by HIP events on its own stream and tagged with its algorithmic FLOPs.
 struct Prof {
     struct Rec { int id; double flops, bytes; hipEvent_t e0, e1; };   // algorithmic FLOPs and HBM bytes (operands read once + result written once)
-    static constexpr int NID = 9;
+    static constexpr int NID = 8;
     std::vector<Rec> recs;
     static const char* name(int id);
     void begin(int id, double flops, double bytes, hipStream_t st);

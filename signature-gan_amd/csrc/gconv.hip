@@ -532,7 +532,7 @@ int exp_knob(const char* name, int dflt) {
 
 const char* Prof::name(int id) {
     static const char* n[NID] = {"k_gconv<128,128>", "k_gconv<128,64>", "k_gconv<64,64>", "k_gconv<128,32>",
-                                 "k_wgrad<64,64>", "k_gconv_up4", "k_wgrad<32,128>", "k_wgrad<64,128>", "?"};
+                                 "k_wgrad<64,64>", "k_gconv_up4", "k_wgrad<32,128>", "?"};
     return n[id < 0 || id >= NID ? NID - 1 : id];
 }
 // The two events of a record are handed to hipExtLaunchKernelGGL, which stamps them with the
@@ -827,43 +827,30 @@ static void launch_wgrad_reduce(const float* slab, float* dw, float* db, int nsp
 int launch_wgrad(WgradArgs a, int max_splits, hipStream_t st) {
     // 64x64 tiles (one 32x32 accumulator per wave keeps the fp32 MFMA pipe full): many tiles,
     // hence few K splits and little slab traffic; Cs == 32 uses a 32x128 tile.
+    // (measured and dropped in round 3, DESIGN 4: 64x128 tiles; three / four workgroups per CU through more K splits)
     const int N = 16 << a.lgCl;
     const bool small = a.Cs < 64;
-    const int ktiles = (a.K + BK - 1) / BK;
-    auto plan = [&](int tiles, int& per) {
-        int nsplit = (512 + tiles - 1) / tiles;              // ~2 workgroups per CU
-        if (nsplit > ktiles / 4) nsplit = ktiles / 4;        // at least 4 K-tiles per split
-        if (nsplit > max_splits) nsplit = max_splits;
-        if (nsplit < 1) nsplit = 1;
-        per = (ktiles + nsplit - 1) / nsplit;
-        return (ktiles + per - 1) / per;
-    };
-    int tiles = small ? (N / 128) : (a.Cs / 64) * (N / 64);
-    int per, nsplit = plan(tiles, per);
-    // 64x128 tiles (two accumulators per wave: half the S traffic and twice the matrix-pipe time per staged K-tile) for the
-    // fp32 layers whose K is split anyway: the tile count halves and the split count doubles, the grid stays the same
-    bool wide = false;
-    if (!small && a.dt == DT_F32 && nsplit >= 2 && exp_knob("SIGGAN_X_WGRAD_WIDE", 0)) {
-        int per2; const int t2 = tiles / 2, ns2 = plan(t2, per2);
-        if (ns2 * t2 >= nsplit * tiles - tiles / 2 && per2 >= 8) { wide = true; tiles = t2; per = per2; nsplit = ns2; }
-    }
+    const int tiles = small ? (N / 128) : (a.Cs / 64) * (N / 64);
+    int ktiles = (a.K + BK - 1) / BK;
+    int nsplit = (512 + tiles - 1) / tiles;                  // ~2 workgroups per CU
+    if (nsplit > ktiles / 4) nsplit = ktiles / 4;            // at least 4 K-tiles per split
+    if (nsplit > max_splits) nsplit = max_splits;
+    if (nsplit < 1) nsplit = 1;
+    int per = (ktiles + nsplit - 1) / nsplit;
     a.kchunk = per * BK;
+    nsplit = (ktiles + per - 1) / per;
     dim3 grid(tiles, 1, nsplit);
-    const int pid = small ? 6 : (wide ? 7 : 4);
+    if (g_prof) g_prof->begin(small ? 6 : 4, 2.0 * a.Cs * (double)N * a.K, wgrad_bytes(a), st);
+    hipEvent_t e0 = g_prof ? g_prof->recs.back().e0 : nullptr, e1 = g_prof ? g_prof->recs.back().e1 : nullptr;
     if (a.dt != DT_F32) {
-        if (g_prof) g_prof->begin(pid, 2.0 * a.Cs * (double)N * a.K, wgrad_bytes(a), st);
-        launch_wgrad16(small, a, grid, st, g_prof ? g_prof->recs.back().e0 : nullptr, g_prof ? g_prof->recs.back().e1 : nullptr);
+        launch_wgrad16(small, a, grid, st, e0, e1);
+    } else if (g_prof) {
+        if (small) hipExtLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL((k_wgrad<64, 64, 2, 2>), grid, dim3(256), 0, st, e0, e1, 0, a);
+    } else if (small) {
+        hipLaunchKernelGGL((k_wgrad<32, 128, 1, 4>), grid, dim3(256), 0, st, a);
     } else {
-#define WG_LAUNCH(...)                                                                                              \
-        do {                                                                                                        \
-            if (g_prof) hipExtLaunchKernelGGL((k_wgrad<__VA_ARGS__>), grid, dim3(256), 0, st, g_prof->recs.back().e0, g_prof->recs.back().e1, 0, a); \
-            else hipLaunchKernelGGL((k_wgrad<__VA_ARGS__>), grid, dim3(256), 0, st, a);                              \
-        } while (0)
-        if (g_prof) g_prof->begin(pid, 2.0 * a.Cs * (double)N * a.K, wgrad_bytes(a), st);
-        if (small) WG_LAUNCH(32, 128, 1, 4);
-        else if (wide) WG_LAUNCH(64, 128, 2, 2);
-        else WG_LAUNCH(64, 64, 2, 2);
-#undef WG_LAUNCH
+        hipLaunchKernelGGL((k_wgrad<64, 64, 2, 2>), grid, dim3(256), 0, st, a);
     }
     if (nsplit > 1) launch_wgrad_reduce(a.slab, a.dw, a.db, nsplit, a.Cs, 1 << a.lgCl, st);
     return nsplit;

@@ -81,10 +81,6 @@ void launch_fc_wgrad(int dt, const void* dy, const float* z, float* dW, float* d
 void launch_bn_train_stats(int dt, const void* y, int64_t R, int C, const float* gamma, const float* beta,
                            float* rmean, float* rvar, int64_t* batches, float* bn, float* partial,
                            int perm_c0, float momentum, float eps, hipStream_t s);
-// the same plus a = relu(y*scale + shift) (a == nullptr: statistics only) in ONE launch for the small layers (a workgroup per
-// float4 channel group over all rows); returns false -- nothing launched -- when the layer is not one of them
-bool launch_bn_train_fused(int dt, const void* y, void* a, int64_t R, int C, const float* gamma, const float* beta, float* rmean,
-                           float* rvar, int64_t* batches, float* bn, int perm_c0, float momentum, float eps, hipStream_t s);
 // a = relu(y*scale + shift)
 void launch_bn_relu(int dt, const void* y, void* a, int64_t R, int C, const float* bn, hipStream_t s);
 // backward through relu(BN(y)): da (in) -> dy (in place); dgamma/dbeta (torch order) written.  The relu mask is
@@ -167,6 +163,21 @@ void launch_grad_sumsq(const float* g, int64_t n, DevState* st, float* partial, 
 void launch_adam_prepare(DevState* st, float* steps, int ntensors, double lr, double beta1, double beta2,
                          float grad_scale, float clip_max_norm, float* metric_norm, hipStream_t s,
                          int check_finite = 0, float* metric_skipped = nullptr);
+// beta^t for an integer-valued step count by repeated squaring in double: the SAME arithmetic on the host (fused path below)
+// and on the device (k_adam_prepare), so the two paths give bit-identical bias corrections (within an ulp of libm's pow,
+// which torch's Python-side `beta ** step` uses)
+__host__ __device__ inline double pow_step(double b, double t) {
+    unsigned long long n = (unsigned long long)t;
+    double r = 1.0;
+    while (n) { if (n & 1) r *= b; b *= b; n >>= 1; }
+    return r;
+}
+// One-launch optimiser update (no k_adam_prepare in front): the caller knows the step count `t` (AFTER the increment) on the
+// host and passes the bias-corrected scalars; the kernel derives the clip coefficient from DevState::sumsq itself, block 0
+// writes steps[0..ntensors) = t, ticks the RNG epoch and stores the pre-clip norm.  Same update arithmetic as launch_adam.
+void launch_adam_fused(float* p, float* g, float* m, float* v, int64_t n, DevState* st, float* steps, int ntensors, double t,
+                       double lr, double beta1, double beta2, double eps, float grad_scale, float clip_max_norm,
+                       float* metric_norm, hipStream_t s);
 void launch_adam(float* p, float* g, float* m, float* v, int64_t n, const DevState* st, double beta1,
                  double beta2, double eps, int write_back_grad, hipStream_t s);
 

@@ -267,117 +267,6 @@ struct FBnBwd {   // relu mask re-derived from y (a > 0 <=> fma(y, scale, shift)
 // =========================================================================================
 // BatchNorm
 // =========================================================================================
-// ---- small layers: ONE workgroup owns a float4 channel group over ALL R rows, so statistics, finalize and apply are one
-// launch (no partial rows, no finalize kernel): the Generator's 8x8 / 16x16 blocks, whose three-launch chains are pure launch
-// latency.  The second pass re-reads the (L2-resident) tensor.  1024 threads; sums: thread-strided, then waves, then LDS.
-__device__ __forceinline__ void block_sum8(f32x4& a, f32x4& b, f32x4 (*sh)[2]) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { a[k] += __shfl_xor(a[k], o); b[k] += __shfl_xor(b[k], o); }
-    }
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) { sh[w][0] = a; sh[w][1] = b; }
-    __syncthreads();
-    if (w == 0) {                                   // the 16 wave sums: one more shuffle tree in wave 0
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 x = lane < 16 ? sh[lane][0] : z, y = lane < 16 ? sh[lane][1] : z;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { x[k] += __shfl_xor(x[k], o); y[k] += __shfl_xor(y[k], o); }
-        }
-        if (lane == 0) { sh[0][0] = x; sh[0][1] = y; }
-    }
-    __syncthreads();
-    a = sh[0][0]; b = sh[0][1];
-}
-template <class T>
-__global__ __launch_bounds__(1024) void k_bn_fwd_small(const T* __restrict__ y, T* __restrict__ a, int R, int C,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float* __restrict__ rmean, float* __restrict__ rvar,
-                                                       int64_t* __restrict__ batches, float* __restrict__ bn, float momentum,
-                                                       float eps) {
-    __shared__ f32x4 sh[16][2];
-    const int c0 = blockIdx.x * 4;
-    const T* col = y + c0;
-    const f32x4 p = ld4<T>(col);                                      // shift: the first row (robust single-pass variance)
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-#pragma unroll 2
-    for (int r = threadIdx.x; r < R; r += 1024) {
-        const f32x4 d = ld4<T>(col + (size_t)r * C) - p;
-        s0 += d;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s1[k] = fmaf(d[k], d[k], s1[k]);
-    }
-    block_sum8(s0, s1, sh);
-    const float invR = 1.0f / (float)R;
-    f32x4 sc, sf;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float d = s0[k] * invR, mean = p[k] + d;
-        float var = s1[k] * invR - d * d;
-        var = var > 0.f ? var : 0.f;
-        const float rstd = 1.0f / sqrtf(var + eps);
-        sc[k] = gamma[c0 + k] * rstd; sf[k] = beta[c0 + k] - mean * sc[k];
-        if (threadIdx.x == 0) {
-            const int c = c0 + k;
-            bn[c] = sc[k]; bn[C + c] = sf[k]; bn[2 * C + c] = mean; bn[3 * C + c] = rstd;
-            const float unb = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
-            rmean[c] = momentum * mean + (1.0f - momentum) * rmean[c];
-            rvar[c] = momentum * unb + (1.0f - momentum) * rvar[c];
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && batches) batches[0] += 1;
-    if (!a) return;
-#pragma unroll 2
-    for (int r = threadIdx.x; r < R; r += 1024) {
-        const f32x4 v = ld4<T>(col + (size_t)r * C);
-        st4<T>(a + c0 + (size_t)r * C, f32x4{fmaxf(fmaf(v[0], sc[0], sf[0]), 0.f), fmaxf(fmaf(v[1], sc[1], sf[1]), 0.f),
-                                            fmaxf(fmaf(v[2], sc[2], sf[2]), 0.f), fmaxf(fmaf(v[3], sc[3], sf[3]), 0.f)});
-    }
-}
-template <class T>
-__global__ __launch_bounds__(1024) void k_bn_bwd_small(T* __restrict__ da, const T* __restrict__ y, int R, int C,
-                                                       float* __restrict__ bn, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta) {
-    __shared__ f32x4 sh[16][2];
-    const int c0 = blockIdx.x * 4;
-    const f32x4 sc = ld4<float>(bn + c0), sf = ld4<float>(bn + C + c0), mu = ld4<float>(bn + 2 * C + c0), rs = ld4<float>(bn + 3 * C + c0);
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-#pragma unroll 4
-    for (int r = threadIdx.x; r < R; r += 1024) {
-        const f32x4 g = ld4<T>(da + c0 + (size_t)r * C), v = ld4<T>(y + c0 + (size_t)r * C);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float d = fmaf(v[k], sc[k], sf[k]) > 0.f ? g[k] : 0.f;
-            s0[k] += d;
-            s1[k] = fmaf(d, (v[k] - mu[k]) * rs[k], s1[k]);
-        }
-    }
-    block_sum8(s0, s1, sh);
-    const float invR = 1.0f / (float)R;
-    const f32x4 c1 = s0 * invR, c2 = s1 * invR;
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { dbeta[c0 + k] = s0[k]; dgamma[c0 + k] = s1[k]; bn[4 * C + c0 + k] = c1[k]; bn[5 * C + c0 + k] = c2[k]; }
-    }
-#pragma unroll 4
-    for (int r = threadIdx.x; r < R; r += 1024) {
-        const f32x4 g = ld4<T>(da + c0 + (size_t)r * C), v = ld4<T>(y + c0 + (size_t)r * C);
-        f32x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            o[k] = sc[k] * ((fmaf(v[k], sc[k], sf[k]) > 0.f ? g[k] : 0.f) - c1[k] - (v[k] - mu[k]) * rs[k] * c2[k]);
-        st4<T>(da + c0 + (size_t)r * C, o);
-    }
-}
-// the one-launch kernels cover a layer when every workgroup's column is small enough to stay in L2 between its two passes
-// and there are enough columns to occupy a few CUs
-static bool bn_small(int64_t R, int C, int perm_c0) {
-    return perm_c0 == 0 && C >= 64 && (C & 3) == 0 && R <= 16384 && exp_knob("SIGGAN_X_BN_SMALL", 1) != 0;
-}
-
 template <int W, class T>
 __global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int64_t R, int C,
                                const T* __restrict__ y, const float* __restrict__ gamma,
@@ -402,13 +291,6 @@ __global__ __launch_bounds__(1024) void k_bn_train_fin(const float* __restrict__
     const float unb = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
     rmean[t] = momentum * mean + (1.0f - momentum) * rmean[t];
     rvar[t] = momentum * unb + (1.0f - momentum) * rvar[t];
-}
-bool launch_bn_train_fused(int dt, const void* yv, void* av, int64_t R, int C, const float* gamma, const float* beta, float* rmean,
-                           float* rvar, int64_t* batches, float* bn, int perm_c0, float momentum, float eps, hipStream_t s) {
-    if (!bn_small(R, C, perm_c0)) return false;
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_bn_fwd_small<T>, dim3(C / 4), dim3(1024), 0, s, (const T*)yv, (T*)av, (int)R, C, gamma, beta,
-                                                rmean, rvar, batches, bn, momentum, eps));
-    return true;
 }
 void launch_bn_train_stats(int dt, const void* yv, int64_t R, int C, const float* gamma, const float* beta, float* rmean,
                            float* rvar, int64_t* batches, float* bn, float* partial, int perm_c0, float momentum,
@@ -478,11 +360,6 @@ __global__ void k_bn_bwd_apply(T* __restrict__ da, const T* __restrict__ y, int6
 }
 void launch_bn_bwd(int dt, void* dav, const void* yv, int64_t R, int C, float* bn, float* partial,
                    float* dgamma, float* dbeta, int perm_c0, hipStream_t s) {
-    if (bn_small(R, C, perm_c0)) {
-        SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_bn_bwd_small<T>, dim3(C / 4), dim3(1024), 0, s, (T*)dav, (const T*)yv, (int)R, C, bn,
-                                                    dgamma, dbeta));
-        return;
-    }
     const ColPlan pl = col_plan(R, C);
     float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
     const int64_t n4 = R * C / 4;
@@ -774,14 +651,29 @@ __global__ __launch_bounds__(256) void k_final_bwd_reduce(const float* __restric
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = f4v{0.f, 0.f, 0.f, 0.f};
     float sdb = 0.f;
+    // the y rows of the NEXT strip are requested before the current strip is reduced (a block walks several strips when the
+    // launcher caps the grid): the loads of strip i+1 fly under the ~300 FMAs per row of strip i
+    f4v yn[RY];
+    {
+        const StripId t0 = strip_of<RY>(blockIdx.x < (unsigned)nstrips ? blockIdx.x : 0, S, threadIdx.x >> 3);
+        const T* yb = y + (((size_t)t0.n * S + t0.y0) * S + t0.x) * C + c4 * 4;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) yn[r] = ld4<T>(yb + (size_t)r * S * C);
+    }
     for (int sid = blockIdx.x; sid < nstrips; sid += gridDim.x) {
         const StripId t = strip_of<RY>(sid, S, threadIdx.x >> 3);
         float d[RY + 2][3];
         load_dpre_strip<RY>(dpre, t, S, d);
-        const T* ybase = y + (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
         f4v yv[RY];
 #pragma unroll
-        for (int r = 0; r < RY; ++r) yv[r] = ld4<T>(ybase + (size_t)r * S * C);
+        for (int r = 0; r < RY; ++r) yv[r] = yn[r];
+        {
+            const int nx = sid + gridDim.x < nstrips ? sid + gridDim.x : sid;
+            const StripId tn = strip_of<RY>(nx, S, threadIdx.x >> 3);
+            const T* yb = y + (((size_t)tn.n * S + tn.y0) * S + tn.x) * C + c4 * 4;
+#pragma unroll
+            for (int r = 0; r < RY; ++r) yn[r] = ld4<T>(yb + (size_t)r * S * C);
+        }
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             const f4v g = final_dact<RY>(d, w, r);
@@ -880,20 +772,18 @@ __global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ par
     if (threadIdx.x >= 64 || j >= width) return;
     if (j < n0) o0[j] = s; else o1[j - n0] = s;
 }
-// rows per strip of k_final_bwd_reduce: 8 (256 VGPRs) or 4 (188)
-static int final_ry() { return exp_knob("SIGGAN_X_FINAL_RY", 4) == 8 ? 8 : 4; }
+// rows per strip of k_final_bwd_reduce: 4 (8-row strips need 256 registers and measured 36 vs 26 us)
+constexpr int FINAL_RY = 4;
 static int final_reduce_rows(int B, int S) {
     const int cap = exp_knob("SIGGAN_X_FINAL_ROWS", 1024);
-    const int n = B * (S / final_ry()) * (S / 32); return n < cap ? n : cap;
+    const int n = B * (S / FINAL_RY) * (S / 32); return n < cap ? n : cap;
 }
 void launch_final_bwd_reduce(int dt, const float* dpre, const float* W, const void* y, int B, int S, int C, const float* bn,
                              float* partial, float* partial_w, hipStream_t s) {
-    const int ry = final_ry(), nstrips = B * (S / ry) * (S / 32), nch = final_reduce_rows(B, S);
+    const int nstrips = B * (S / FINAL_RY) * (S / 32), nch = final_reduce_rows(B, S);
     float* p0 = partial; float* p1 = partial + (size_t)nch * C;
-    SIGGAN_DT_SWITCH(dt, T, {
-        if (ry == 8) hipLaunchKernelGGL((k_final_bwd_reduce<T, 8>), dim3(nch), dim3(256), 0, s, dpre, W, (const T*)y, bn, p0, p1, partial_w, S, nstrips);
-        else hipLaunchKernelGGL((k_final_bwd_reduce<T, 4>), dim3(nch), dim3(256), 0, s, dpre, W, (const T*)y, bn, p0, p1, partial_w, S, nstrips);
-    });
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL((k_final_bwd_reduce<T, FINAL_RY>), dim3(nch), dim3(256), 0, s, dpre, W, (const T*)y, bn, p0, p1,
+                                                partial_w, S, nstrips));
 }
 void launch_final_wgrad_fin(const float* partial_w, float* dW, float* db, int B, int S, int C, hipStream_t s) {
     hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 64)), dim3(1024), 0, s, partial_w, final_reduce_rows(B, S), C * 9 + 1, dW, C * 9, db);
@@ -973,11 +863,13 @@ void launch_conv1_fwd(int dt, const float* x0, int n0, const float* x1, const fl
 // dW[co][kh][kw] = sum dv[n][oh][ow][co] * x[n][2oh-1+kh][2ow-1+kw];  db[co] = sum dv.
 // Same thread map as the forward; 17 x 4 sums per thread, folded over the 16 pixel lanes at the end
 // (shuffles, then LDS across the waves); partial row = [C*16 weights (co*16 + tap)] [C biases].
-template <class T>
+// UP: every load of a strip is issued before the first FMA (PT float4 per thread in flight instead of 4: one round of memory
+// latency per strip instead of PT / 4)
+template <class T, int RY, int PT, bool UP>
 __global__ __launch_bounds__(256) void k_conv1_wgrad(const T* __restrict__ dv, const float* __restrict__ x0, int n0,
                                                      const float* __restrict__ x1, float* __restrict__ partial, int S,
                                                      int nstrips) {
-    constexpr int RY = 8, C = 64;
+    constexpr int C = 64;
     __shared__ float sx[(2 * RY + 2) * 130];
     __shared__ float sh[4][16][69];
     const int Ho = S >> 1, nby = Ho / RY, Wp = S + 2;
@@ -991,6 +883,25 @@ __global__ __launch_bounds__(256) void k_conv1_wgrad(const T* __restrict__ dv, c
         stage_x<RY>(sx, seg_ptr(x0, n0, x1, n, S), oh0, S);
         __syncthreads();
         const T* gbase = dv + ((size_t)n * Ho + oh0) * Ho * C + q * 4;
+        if (UP) {                                       // (PT = RY * Ho / 16 pixels per thread, compile-time)
+            f4v g[PT];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) g[u] = ld4<T>(gbase + (size_t)(pl + 16 * u) * C);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                const int p = pl + 16 * u, r = p / Ho, ow = p - r * Ho;
+                const float* xr = sx + (2 * r) * Wp + 2 * ow;
+                acc[16] += g[u];
+#pragma unroll
+                for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 4; ++kw) {
+                        const float xv = xr[kh * Wp + kw];
+                        f4v& a = acc[kh * 4 + kw];
+                        a.x = fmaf(g[u].x, xv, a.x); a.y = fmaf(g[u].y, xv, a.y); a.z = fmaf(g[u].z, xv, a.z); a.w = fmaf(g[u].w, xv, a.w);
+                    }
+            }
+        } else
         for (int p0 = pl; p0 < RY * Ho; p0 += 64) {
             f4v g[4];
 #pragma unroll
@@ -1038,7 +949,11 @@ void launch_conv1_wgrad(int dt, const void* dv, const float* x0, int n0, const f
                         int B, int S, int C, hipStream_t s) {
     const int nstrips = B * (S / 2 / 8);
     const int nch = nstrips < 1024 ? nstrips : 1024;
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_conv1_wgrad<T>, dim3(nch), dim3(256), 0, s, (const T*)dv, x0, n0, x1, partial, S, nstrips));
+    const bool up = S == 64 && exp_knob("SIGGAN_X_C1W_UP", 0) != 0;     // 8 rows x 32 columns / 16 pixel lanes = 16 float4 per thread
+    SIGGAN_DT_SWITCH(dt, T, {
+        if (up) hipLaunchKernelGGL((k_conv1_wgrad<T, 8, 16, true>), dim3(nch), dim3(256), 0, s, (const T*)dv, x0, n0, x1, partial, S, nstrips);
+        else hipLaunchKernelGGL((k_conv1_wgrad<T, 8, 16, false>), dim3(nch), dim3(256), 0, s, (const T*)dv, x0, n0, x1, partial, S, nstrips);
+    });
     hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 17, 64)), dim3(1024), 0, s, partial, nch, C * 17, dW, C * 16, db);
 }
 
@@ -1109,7 +1024,7 @@ void launch_conv1_dgrad_tanh(int dt, const void* dv, const float* W, const float
     (void)C;
     const int Ho = S / 2;
     SIGGAN_DT_SWITCH(dt, T, {
-        if (exp_knob("SIGGAN_X_C1D_RA", 4) == 2)
+        if (exp_knob("SIGGAN_X_C1D_RA", 2) == 2)
             hipLaunchKernelGGL((k_conv1_dgrad_tanh<T, 2>), dim3(B * (Ho / 2) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, W, img, dpre, S);
         else
             hipLaunchKernelGGL((k_conv1_dgrad_tanh<T, 4>), dim3(B * (Ho / 4) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, W, img, dpre, S);
@@ -1350,8 +1265,8 @@ __global__ void k_adam_prepare(DevState* st, float* __restrict__ steps, int nten
     st->rng_ctr += 1;                       // every optimiser update starts a new RNG epoch (z, dropout tables)
     st->skip = skip ? 1 : 0;
     if (metric_skipped) *metric_skipped = skip ? 1.0f : 0.0f;
-    const double bc1 = 1.0 - pow(beta1, (double)t);
-    const double bc2 = 1.0 - pow(beta2, (double)t);
+    const double bc1 = 1.0 - pow_step(beta1, (double)t);
+    const double bc2 = 1.0 - pow_step(beta2, (double)t);
     st->step_size = (float)(lr / bc1);
     st->bc2_sqrt = (float)sqrt(bc2);
     float mul = grad_scale;
@@ -1370,14 +1285,39 @@ void launch_adam_prepare(DevState* st, float* steps, int ntensors, double lr, do
                        clip_max_norm, metric_norm, check_finite, metric_skipped);
 }
 
+struct AdamHost {          // scalars of a fused update, formed on the host (FUSED: no k_adam_prepare ran)
+    float step_size, bc2_sqrt, grad_scale, clip_max_norm, t;
+    int ntensors;
+    float* steps;
+    float* metric_norm;
+};
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                               float4* __restrict__ v, int64_t n4, float* __restrict__ pt,
                                               float* __restrict__ gt, float* __restrict__ mt, float* __restrict__ vt,
-                                              int tail, const DevState* __restrict__ st, float w1, float beta2,
-                                              float w2, float eps, int wb) {
+                                              int tail, DevState* __restrict__ st, float w1, float beta2,
+                                              float w2, float eps, int wb, const AdamHost h) {
     // w1 = (float)(1 - beta1), w2 = (float)(1 - beta2): formed in double on the host, as torch does
-    if (st->skip) return;                   // (uniform: k_adam_prepare found a non-finite fp16 gradient)
-    const float mul = st->grad_mul, ss = -st->step_size, bc2 = st->bc2_sqrt;
+    float mul, ss, bc2;
+    if (FUSED) {
+        mul = h.grad_scale; ss = -h.step_size; bc2 = h.bc2_sqrt;
+        float norm = 0.f;
+        if (h.clip_max_norm > 0.f) {                                   // nn.utils.clip_grad_norm_ (norm_type 2), k_adam_prepare's expression
+            norm = sqrtf(st->sumsq) * h.grad_scale;
+            mul = h.grad_scale * fminf(h.clip_max_norm / (norm + 1e-6f), 1.0f);
+        }
+        if (blockIdx.x == 0) {                                         // what k_adam_prepare does besides the scalars
+            for (int i = threadIdx.x; i < h.ntensors; i += 256) h.steps[i] = h.t;
+            if (threadIdx.x == 0) {
+                st->rng_ctr += 1;                                      // every optimiser update starts a new RNG epoch
+                st->skip = 0;
+                if (h.clip_max_norm > 0.f) { st->grad_norm = norm; if (h.metric_norm) *h.metric_norm = norm; }
+            }
+        }
+    } else {
+        if (st->skip) return;               // (uniform: k_adam_prepare found a non-finite fp16 gradient)
+        mul = st->grad_mul; ss = -st->step_size; bc2 = st->bc2_sqrt;
+    }
     auto upd = [&](float& pp, float& gg, float& mm, float& vv) {
         const float gr = gg * mul;
         gg = gr;
@@ -1403,13 +1343,28 @@ __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __
         if (wb) gt[k] = gg;
     }
 }
+void launch_adam_fused(float* p, float* g, float* m, float* v, int64_t n, DevState* st, float* steps, int ntensors, double t,
+                       double lr, double beta1, double beta2, double eps, float grad_scale, float clip_max_norm,
+                       float* metric_norm, hipStream_t s) {
+    const int64_t n4 = n / 4;
+    const int tail = (int)(n - n4 * 4);
+    AdamHost h;
+    h.step_size = (float)(lr / (1.0 - pow_step(beta1, t)));            // torch.optim.Adam: lr / (1 - beta1**step), in double
+    h.bc2_sqrt = (float)sqrt(1.0 - pow_step(beta2, t));
+    h.grad_scale = grad_scale; h.clip_max_norm = clip_max_norm; h.t = (float)t; h.ntensors = ntensors; h.steps = steps;
+    h.metric_norm = metric_norm;
+    const int wb = (clip_max_norm > 0.f || grad_scale != 1.0f) ? 1 : 0;
+    hipLaunchKernelGGL(k_adam<true>, dim3(cdiv(n4 + tail, 256)), dim3(256), 0, s, (float4*)p, (float4*)g, (float4*)m, (float4*)v,
+                       n4, p + n4 * 4, g + n4 * 4, m + n4 * 4, v + n4 * 4, tail, st, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps, wb, h);
+}
 void launch_adam(float* p, float* g, float* m, float* v, int64_t n, const DevState* st, double beta1, double beta2,
                  double eps, int write_back_grad, hipStream_t s) {
     const int64_t n4 = n / 4;
     const int tail = (int)(n - n4 * 4);
-    hipLaunchKernelGGL(k_adam, dim3(cdiv(n4 + tail, 256)), dim3(256), 0, s, (float4*)p, (float4*)g, (float4*)m, (float4*)v,
-                       n4, p + n4 * 4, g + n4 * 4, m + n4 * 4, v + n4 * 4, tail, st, (float)(1.0 - beta1), (float)beta2,
-                       (float)(1.0 - beta2), (float)eps, write_back_grad);
+    hipLaunchKernelGGL(k_adam<false>, dim3(cdiv(n4 + tail, 256)), dim3(256), 0, s, (float4*)p, (float4*)g, (float4*)m, (float4*)v,
+                       n4, p + n4 * 4, g + n4 * 4, m + n4 * 4, v + n4 * 4, tail, const_cast<DevState*>(st), (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), (float)eps, write_back_grad, AdamHost{});
 }
 
 }  // namespace siggan

@@ -113,11 +113,12 @@ struct PhaseKey {
     int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg, pre_real, variant;
     float* mt;   // where the phase writes its metrics (caller's buffer, or the workspace one)
     double lr, beta1, beta2, eps;
+    double fused_t;   // > 0: the step count (after the increment) of a one-launch optimiser update; 0: k_adam_prepare path
     float ls, clip, gs;
     bool operator==(const PhaseKey& o) const {
         return phase == o.phase && B == o.B && has_z == o.has_z && has_masks == o.has_masks && g_dirty == o.g_dirty &&
                d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && pre_real == o.pre_real && variant == o.variant && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
-               clip == o.clip && gs == o.gs;
+               clip == o.clip && gs == o.gs && fused_t == o.fused_t;
     }
 };
 
@@ -154,7 +155,7 @@ struct siggan_ctx {
     float *logits, *probs, *dlogit;
     char *g_up[MAXL + 1], *g_dn[MAXL + 1], *d_dn[MAXL + 1], *d_up[MAXL + 1];
     float *wcp;
-    float *slab, *slab_k, *slab_k2, *partial, *partial_b, *partial_c, *z_g, *img_g, *metrics, *zeros, *wfc_t, *real_stage, *real_next, *mask_stage;
+    float *slab, *slab_k, *slab_k2, *partial, *partial_b, *partial_c, *z_g, *img_g, *metrics, *zeros, *wfc_t, *real_stage, *mask_stage;
     char *op_pack;
     int64_t slab_floats, slab_k_floats;
     DevState* dev;
@@ -171,10 +172,13 @@ struct siggan_ctx {
     // data-parallel communicator (siggan_comm_init): world 1 = none
     ncclComm_t comm; int comm_rank, comm_world; int comm_err;
     int staged_B;        // batch of a real batch staged for the NEXT D step by siggan_stage_real (0: none)
-    const float* staged_src;   // where that batch lies: the library's copy (real_next), or the caller's own tensor
+    const float* staged_src;   // where that batch lies: the caller's own tensor (borrowed until the D step that consumes it)
     int dreal_B;         // batch whose D(real) forward siggan_g_grads already enqueued on lane c (0: none)
     int zg_stash;        // batch of an explicit G-step z handed to siggan_step_begin when the forward was not pipelined
     int g_fwd_pending;   // batch of a Generator training forward already enqueued by siggan_step_begin (0: none)
+    double adam_t[2];    // step count of the network's Adam state as the HOST knows it ([0] G, [1] D); valid while adam_t_known
+    bool adam_t_known[2];// (reset by siggan_bind / siggan_params_changed: the caller may have written the step tensors)
+    int g_r0;            // first workspace row of the Discriminator pass of the last G step (0, or B: beside an early D(real))
     int ga_last_B;       // batch of the last TRAINING Generator forward: the last block's activation was not materialised
                          // (siggan_debug_tensor("g_a", Lg) forms it on demand)
     hipEvent_t ev[NEV], ev_bridge[2];
@@ -319,7 +323,6 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->z_g, Bm * c->latent);
         carve(&c->img_g, Bm * c->S * c->S);
         carve(&c->real_stage, Bm * c->S * c->S);
-        carve(&c->real_next, Bm * c->S * c->S);
         { int64_t sumC = 0; for (int l = 1; l <= c->Ld; ++l) sumC += c->dC[l]; carve(&c->mask_stage, 3 * Bm * sumC); }
         if (c->sn) {
             int64_t ut = 1, vt = (int64_t)c->dC[c->Ld] * 16;
@@ -362,7 +365,8 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1; c->comm_err = 0;
     c->g_fwd_pending = 0;
     c->zg_stash = 0;
-    c->ga_last_B = 0;
+    c->ga_last_B = 0; c->g_r0 = 0;
+    c->adam_t_known[0] = c->adam_t_known[1] = false;
     for (int i = 0; i < siggan_ctx::NEV; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_bridge[i], hipEventDisableTiming));
     *out = c;
@@ -454,12 +458,14 @@ extern "C" int siggan_bind(siggan_ctx* c, const siggan_storage* st) {
         t.u_saved = c->sn_us; t.v_saved = c->sn_vs; t.dots = c->sn_dots; t.u_total = uo; t.v_total = vo;
     }
     c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0; c->staged_B = 0;
+    c->adam_t_known[0] = c->adam_t_known[1] = false;
     drop_dreal(c);
     return SIGGAN_OK;
 }
 extern "C" int siggan_params_changed(siggan_ctx* c) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     c->g_dirty = c->d_dirty = true;
+    c->adam_t_known[0] = c->adam_t_known[1] = false;      // (optimizer.load_state_dict writes the step tensors)
     drop_dreal(c);                     // a D(real) forward started ahead of time used the old weights
     return SIGGAN_OK;
 }
@@ -596,25 +602,26 @@ static GConvArgs gconv_args(siggan_ctx* c) {
 static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s,
                            float* partial = nullptr, float* slab_k = nullptr, uint32_t rng_sid = 0, float* z_out = nullptr) {
     if (!partial) partial = c->partial;
+    char* const* const A = c->g_a;
     // fc + BatchNorm1d + ReLU: one MFMA launch (fc.hip) whenever the shape allows, else the generic kernels
-    if (c->fc_fused && launch_fc_fwd_fused(c->dt, z, GP(c, gi_fc_w()), GP(c, gi_fc_b()), c->fc_y, c->g_a[0], GP(c, gi_bn0_w()),
+    if (c->fc_fused && launch_fc_fwd_fused(c->dt, z, GP(c, gi_fc_w()), GP(c, gi_fc_b()), c->fc_y, A[0], GP(c, gi_bn0_w()),
                                           GP(c, gi_bn0_b()), c->st.g_bn_running_mean, c->st.g_bn_running_var, c->st.g_bn_batches,
                                           c->g_bn[0], training ? nullptr : c->g_bne[0], z_out, c->dev, rng_sid, B, c->latent,
                                           c->gC[0], BN_MOMENTUM, BN_EPS, s)) {
     } else if (!training) {     // eval: BatchNorm1d + ReLU folded into the fc epilogue
-        launch_fc_fwd(c->dt, z, c->wfc_t, GP(c, gi_fc_b()), c->g_a[0], B, c->latent, c->gC[0], s, c->g_bne[0], c->dev, rng_sid, z_out);
+        launch_fc_fwd(c->dt, z, c->wfc_t, GP(c, gi_fc_b()), A[0], B, c->latent, c->gC[0], s, c->g_bne[0], c->dev, rng_sid, z_out);
     } else {
         launch_fc_fwd(c->dt, z, c->wfc_t, GP(c, gi_fc_b()), c->fc_y, B, c->latent, c->gC[0], s, nullptr, c->dev, rng_sid, z_out);
         launch_bn_train_stats(c->dt, c->fc_y, B, c->F, GP(c, gi_bn0_w()), GP(c, gi_bn0_b()), c->st.g_bn_running_mean,
                               c->st.g_bn_running_var, c->st.g_bn_batches, c->g_bn[0], partial, c->gC[0], BN_MOMENTUM,
                               BN_EPS, s);
-        launch_bn_relu(c->dt, c->fc_y, c->g_a[0], B, c->F, c->g_bn[0], s);
+        launch_bn_relu(c->dt, c->fc_y, A[0], B, c->F, c->g_bn[0], s);
     }
     for (int l = 1; l <= c->Lg; ++l) {
         const int Hi = 4 << (l - 1), Ci = c->gC[l - 1], Co = c->gC[l];
         GConvArgs a = gconv_args(c);
         if (slab_k) a.slab = slab_k;
-        a.in = c->g_a[l - 1]; a.wp = c->g_up[l]; a.B = B; a.Hi = Hi; a.Wi = Hi; a.Ci = Ci; a.Co = Co;
+        a.in = A[l - 1]; a.wp = c->g_up[l]; a.B = B; a.Hi = Hi; a.Wi = Hi; a.Ci = Ci; a.Co = Co;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = 2 * Hi; a.Wo = 2 * Hi; a.form = 1; a.M = B * Hi * Hi;
         const int C = Co;
         const int64_t off = c->g_bn_off[l];
@@ -624,23 +631,19 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
             const int64_t R = (int64_t)B * 4 * Hi * Hi;
             // the LAST block's activation has two readers, the final conv here and its weight gradient in the backward
             // pass: both re-derive it from y and this table, so it is never written (33.5 MB each way at batch 64)
-            void* const act = l < c->Lg ? c->g_a[l] : nullptr;
-            if (!launch_bn_train_fused(c->dt, c->g_y[l], act, R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
-                                       c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], 0, BN_MOMENTUM, BN_EPS, s)) {
-                launch_bn_train_stats(c->dt, c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
-                                      c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
-                                      BN_MOMENTUM, BN_EPS, s);
-                if (act) launch_bn_relu(c->dt, c->g_y[l], act, R, C, c->g_bn[l], s);
-            }
+            launch_bn_train_stats(c->dt, c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
+                                  c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
+                                  BN_MOMENTUM, BN_EPS, s);
+            if (l < c->Lg) launch_bn_relu(c->dt, c->g_y[l], A[l], R, C, c->g_bn[l], s);
         } else {
-            a.out = c->g_a[l]; a.epi = EPI_AFFINE_RELU; a.scale = c->g_bne[l]; a.shift = c->g_bne[l] + C;
+            a.out = A[l]; a.epi = EPI_AFFINE_RELU; a.scale = c->g_bne[l]; a.shift = c->g_bne[l] + C;
             launch_gconv(a, s);
         }
     }
     if (training)
         launch_final_fwd(c->dt, c->g_y[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s, c->g_bn[c->Lg]);
     else
-        launch_final_fwd(c->dt, c->g_a[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
+        launch_final_fwd(c->dt, A[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
     c->ga_last_B = training ? B : 0;
 }
 
@@ -685,32 +688,27 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
     const float* const w1 = c->sn ? c->d_w1s : DP(c, di_w(1));
     // sigmoid + BCE: losses / means into the metrics, d(logit) for the classifier's weight gradient -- on lane b; the
     // chain below recomputes d(logit) from the logits and does not wait for it
-    // (experiment switches, see DESIGN 4: every fork is an event record on the main lane, and the kernel behind it starts
-    // ~6 us late; a join whose event completes just before it is waited for costs ~15 us)
-    const int x_dbwd = want_wgrad ? exp_knob("SIGGAN_X_DBWD", 0) : 0;          // D step: 1 = weight gradients on the main lane; 2 = no side lane at all
-    const bool bce_main = (!want_wgrad && exp_knob("SIGGAN_X_GBCE_MAIN", 0)) || x_dbwd == 2;
-    hipStream_t const sb = bce_main ? L.m : L.b;
-    hipStream_t const sa = x_dbwd >= 1 ? L.m : L.a;
+    // Lanes: an event record on the main lane delays the kernel behind it by ~6 us and a join whose event
+    // completes just before it is waited for costs ~15 us, so a side lane must carry enough work to pay for its fork and
+    // join.  D step: the weight gradients (lane a: they overlap the input-gradient chain, putting them on the main lane costs
+    // 3 %) and the small reductions (lane b).  G step: nothing here is worth a lane -- the 5 us loss kernel stays on m.
+    hipStream_t const sb = want_wgrad ? L.b : L.m;
     if (sb != L.m) L.fork(L.b);
     launch_bce(c->logits + r0, Bd, bce.n0, bce.y0, bce.y1, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, sb, c->gscale);
     launch_cls_bwd(c->dt, c->logits + r0, bce.n0, bce.y0, bce.y1, c->wcp, act(Ld), nz(Ld), slope, dvp(Ld), Bd,
                    c->dC[Ld], L.m, c->gscale);
     if (want_wgrad)
         launch_cls_wgrad(c->dt, c->dlogit + r0, act(Ld), G_(di_cls_w(c)), G_(di_cls_b(c)), Bd, c->dC[Ld], sb);
-    auto wgrad_of = [&](int l) {
-        const int Ho = c->S >> l, Co = c->dC[l], Ci = c->dC[l - 1];
-        WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
-        w.S = dvp(l); w.L = act(l - 1); w.slab = c->slab; w.dw = G_(di_w(l)); w.B = Bd; w.Cs = Co; w.Cl = Ci;
-        w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
-        w.db = G_(di_b(l));                              // bias gradient = column sums of d(pre-activation): rides in the same kernel
-        const int max_splits = (int)(c->slab_floats / ((int64_t)Co * (16 * Ci + 1)));
-        launch_wgrad(w, max_splits, sa);
-    };
     for (int l = Ld; l >= 2; --l) {
         const int Ho = c->S >> l, Hi = 2 * Ho, Co = c->dC[l], Ci = c->dC[l - 1];
-        if (want_wgrad && x_dbwd == 0) {
+        if (want_wgrad) {
             L.fork(L.a);                                   // d_dv[l] is complete on m here
-            wgrad_of(l);
+            WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
+            w.S = dvp(l); w.L = act(l - 1); w.slab = c->slab; w.dw = G_(di_w(l)); w.B = Bd; w.Cs = Co; w.Cl = Ci;
+            w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
+            w.db = G_(di_b(l));                              // bias gradient = column sums of d(pre-activation): rides in the same kernel
+            const int max_splits = (int)(c->slab_floats / ((int64_t)Co * (16 * Ci + 1)));
+            launch_wgrad(w, max_splits, L.a);
         }
         // input gradient ("up" form): contract Cout, produce Cin at (Hi x Hi); fused leaky'/dropout of block l-1
         GConvArgs a = gconv_args(c);
@@ -719,14 +717,13 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
         a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 1; a.M = Bd * Ho * Ho;
         a.epi = EPI_LRELU_BWD; a.aref = act(l - 1); a.noise = nz(l - 1); a.slope = slope;
         launch_gconv(a, L.m);
-        if (want_wgrad && x_dbwd >= 1) wgrad_of(l);        // behind the input gradient on the same lane (the slab is reused in order)
     }
     if (want_wgrad) {
-        if (sb != L.m) L.fork(L.b);
-        launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], sb);
-        if (sa != L.m) L.join(L.a);
+        L.fork(L.b);
+        launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
+        L.join(L.a);
+        L.join(L.b);
     }
-    if (sb != L.m) L.join(L.b);
     if (want_dimage)
         launch_conv1_dgrad_tanh(c->dt, dvp(1), w1, x0, c->dpre, Bd, c->S, c->dC[1], L.m);
 }
@@ -735,53 +732,39 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
 // BatchNorm backward and the input-gradient chain; lane a: the weight gradients.
 static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     const int Lg = c->Lg, S = c->S;
-    // experiment switch: 0 = one fork per block (each weight gradient starts as soon as its dy exists); 1 = one fork per TWO
-    // blocks; 2 = weight gradients on the main lane (no side lane a); 3 = ONE fork, after the whole chain
-    const int x_gfork = exp_knob("SIGGAN_X_GFORK", 0);
-    const bool fin_main = exp_knob("SIGGAN_X_GFIN_MAIN", 0) != 0;    // the final conv's gradient row sums on the main lane (no lane b)
-    int pending[MAXL + 1], npend = 0;
-    auto wgrad_of = [&](int l, hipStream_t st) {
-        const int Hi = 4 << (l - 1), Ci = c->gC[l - 1], Co = c->gC[l];
-        // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
-        WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
-        w.S = c->g_a[l - 1]; w.L = c->g_da[l]; w.slab = c->slab; w.dw = GG(c, gi_up_w(l)); w.B = B; w.Cs = Ci; w.Cl = Co;
-        w.lgHs = ilog2i(Hi); w.lgWs = w.lgHs; w.lgCl = ilog2i(Co); w.K = B * Hi * Hi;
-        const int max_splits = (int)(c->slab_floats / ((int64_t)Ci * (16 * Co + 1)));
-        launch_wgrad(w, max_splits, st);
-    };
-    auto flush = [&]() { if (npend) { L.fork(L.a); for (int i = 0; i < npend; ++i) wgrad_of(pending[i], L.a); npend = 0; } };
     for (int l = Lg; l >= 1; --l) {
         const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
         const int64_t R = (int64_t)B * Ho * Ho;
         if (l == Lg) {   // final conv's input-gradient folded into this block's BatchNorm backward; its weight gradient rides in
-                         // the same pass over y (the row sums of that gradient go to lane b)
+                         // the same pass over y and its row sums stay on this lane (a 5 us kernel does not pay for a fork + join)
             launch_final_bwd_reduce(c->dt, c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b, L.m);
-            if (!fin_main) L.fork(L.b);
-            launch_final_wgrad_fin(c->partial_b, GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), B, S, Co, fin_main ? L.m : L.b);
+            launch_final_wgrad_fin(c->partial_b, GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), B, S, Co, L.m);
             launch_final_bn_bwd_apply(c->dt, c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
                                       GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
         } else
             launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m);
-        // dy[l] is complete on m here
-        pending[npend++] = l;
-        if (x_gfork == 0 || (x_gfork == 1 && ((Lg - l) & 1) == 1)) flush();
+        L.fork(L.a);                                       // dy[l] is complete on m here
+        // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
+        // (one fork per block; per two blocks measured the same, weight gradients on the main lane 2.5 % slower: DESIGN 4)
+        WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
+        w.S = c->g_a[l - 1]; w.L = c->g_da[l]; w.slab = c->slab; w.dw = GG(c, gi_up_w(l)); w.B = B; w.Cs = Ci; w.Cl = Co;
+        w.lgHs = ilog2i(Hi); w.lgWs = w.lgHs; w.lgCl = ilog2i(Co); w.K = B * Hi * Hi;
+        const int max_splits = (int)(c->slab_floats / ((int64_t)Ci * (16 * Co + 1)));
+        launch_wgrad(w, max_splits, L.a);
         // input gradient ("down" form): out = Cin at Hi, contract Cout over 16 taps
         GConvArgs a = gconv_args(c);
         a.in = c->g_da[l]; a.wp = c->g_dn[l]; a.out = c->g_da[l - 1];
         a.B = B; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
         launch_gconv(a, L.m);
-        if (x_gfork == 2) { for (int i = 0; i < npend; ++i) wgrad_of(pending[i], L.m); npend = 0; }
     }
-    if (x_gfork != 2) flush();
     if (!(c->fc_fused && launch_fc_bwd_fused(c->dt, c->g_da[0], c->fc_y, z, c->g_bn[0], GG(c, gi_fc_w()), GG(c, gi_fc_b()),
                                              GG(c, gi_bn0_w()), GG(c, gi_bn0_b()), B, c->latent, c->gC[0], L.m))) {
         launch_bn_bwd(c->dt, c->g_da[0], c->fc_y, B, c->F, c->g_bn[0], c->partial, GG(c, gi_bn0_w()), GG(c, gi_bn0_b()),
                       c->gC[0], L.m);
         launch_fc_wgrad(c->dt, c->g_da[0], z, GG(c, gi_fc_w()), GG(c, gi_fc_b()), B, c->latent, c->gC[0], L.m);
     }
-    if (x_gfork != 2) L.join(L.a);
-    if (!fin_main) L.join(L.b);
+    L.join(L.a);
 }
 
 // dropout multiplier tables of passes [p0, p1) (pass 0 = rows [0,B) = D(real), pass 1 = rows [B,2B) = D(fake)).
@@ -866,6 +849,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // (siggan_stage_real) beside its Generator backward; then bce only has to wait for that lane
     if (k.pre_real != 2) d_forward_rows(c, c->real_stage, 0, B, drop, L.a, c->slab_k2);
     const float* fake = c->img;
+    const bool spec_fwd = k.spec_g && k.variant != SIGGAN_STEP_ABLATION;
     if (k.variant == SIGGAN_STEP_ABLATION) {
         // ablation_vanilla_gan_signatures.py:397-448: both nets in train mode and ONE Generator forward per iteration --
         // BatchNorm batch statistics (+ running update), activations kept: the D half sees fake.detach(), the G half
@@ -881,8 +865,8 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // runs on its own lane beside D(fake) and the D step's backward (after the eval forward above: it
     // moves the BatchNorm running statistics and reuses the activation buffers; its own image / z /
     // scratch).  It forks HERE but is enqueued after D(fake), whose kernels the dispatcher should see first.
+    // (starting it earlier still, beside the eval forward with activation buffers of its own, measured 0.8 % slower: DESIGN 4)
     hipEvent_t e_spec = nullptr;
-    const bool spec_fwd = k.spec_g && k.variant != SIGGAN_STEP_ABLATION;
     if (spec_fwd) { e_spec = L.next(); L.record(e_spec, L.m); }
     d_forward_rows(c, fake, B, B, drop, L.m, c->slab_k);             // D(fake) into rows [B, 2B)
     if (k.pre_real == 2) L.wait(L.m, c->ev_dreal);
@@ -923,9 +907,23 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         make_noise(c, k.has_masks ? c->mask_stage + (int64_t)2 * B * sumC : nullptr, B, 0, 1, L.m);
     }
     const float gy = abl ? k.ls : 1.0f;
-    d_forward_rows(c, img, 0, B, gdrop, L.m, c->slab_k);
-    d_backward_pass(c, L, img, B, img, B, gdrop, false, true, BceSpec{B, gy, gy, k.mt, 1});   // through D into the image; no D weight grads
-    if (k.pre_real) {
+    // The G step's Discriminator pass runs in workspace rows [B, 2B) -- free since the D step's backward -- so that the NEXT D
+    // step's D(real) forward (rows [0, B), siggan_stage_real) can start right here, beside this pass's forward and
+    // input-gradient chain (one B-sized GEMM at a time leaves half the chip's wave slots idle), not only beside the Generator
+    // backward: +1.3 % (round 3).  (ablation step: its dropout tables are drawn for rows [0, B); spectral norm: no staging)
+    const int r0g = (!abl && !c->sn) ? B : 0;
+    c->g_r0 = r0g;
+    const bool real_early = k.pre_real && r0g != 0;
+    if (real_early) {
+        const bool drop = c->cfg.dropout > 0.f;
+        L.fork(c->s_c);                                               // D's packs are complete on m here
+        if (drop) make_noise(c, nullptr, B, 0, 1, c->s_c, 1);
+        d_forward_rows(c, c->staged_src, 0, B, drop, c->s_c, c->slab_k2);
+        L.record(c->ev_dreal, c->s_c);
+    }
+    d_forward_rows(c, img, r0g, B, gdrop, L.m, c->slab_k);
+    d_backward_pass(c, L, img, B, img, B, gdrop, false, true, BceSpec{B, gy, gy, k.mt, 1}, r0g);   // through D into the image; no D weight grads
+    if (k.pre_real && !real_early) {
         // siggan_stage_real: the NEXT D step's D(real) forward needs the Discriminator as it is now (its
         // update is behind us) and the activation rows this step is done with: run it on lane c beside the
         // Generator backward.  Its dropout tables are drawn for the step counter that step will see (+1:
@@ -966,6 +964,13 @@ static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     }
     const bool guard = c->dt == DT_F16;                              // static gradient scale: skip the update on an overflow
     if (clip || guard) launch_grad_sumsq(g, n, c->dev, c->partial, L.m);
+    if (k.fused_t > 0.0) {
+        // ONE launch: the host knows the step count (apply_common), so the bias corrections are kernel arguments and
+        // k_adam_prepare (a 5 us kernel plus a kernel boundary on the step's critical lane, twice per step) is not needed
+        launch_adam_fused(p, g, m, v, n, c->dev, steps, nt, k.fused_t, k.lr, k.beta1, k.beta2, k.eps, gs, k.clip,
+                          k.mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), L.m);
+        return;
+    }
     launch_adam_prepare(c->dev, steps, nt, k.lr, k.beta1, k.beta2, gs, k.clip,
                         k.mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), L.m, guard ? 1 : 0,
                         k.mt + (which == 0 ? SIGGAN_M_G_SKIPPED : SIGGAN_M_D_SKIPPED));
@@ -1148,14 +1153,11 @@ extern "C" int siggan_stage_real(siggan_ctx* c, const float* real_dev, int32_t b
     int rc = check_call(c, batch);
     if (rc) return rc;
     if (!real_dev) return fail(SIGGAN_E_INVALID, "null real batch");
-    drop_dreal(c);                     // an early D(real) forward of a previously staged batch still reads real_next
+    drop_dreal(c);                     // an early D(real) forward of a previously staged batch may still be reading that batch
     if ((rc = settle(c, (hipStream_t)stream))) return rc;
-    if (exp_knob("SIGGAN_X_STAGE_PTR", 0)) {
-        c->staged_src = real_dev;      // borrowed: the caller keeps the tensor alive and unmodified until the next D step has taken it
-    } else {
-        HIPCHK(hipMemcpyAsync(c->real_next, real_dev, (size_t)batch * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        c->staged_src = c->real_next;
-    }
+    // borrowed, not copied (a 1 MB copy on the step's critical lane): the caller keeps the tensor alive and unmodified until the
+    // D step that consumes it has returned (include/siggan.h); that step copies it into the workspace on a side lane
+    c->staged_src = real_dev;
     c->staged_B = batch;
     return SIGGAN_OK;
 }
@@ -1187,8 +1189,24 @@ static int apply_common(siggan_ctx* c, int which, const siggan_hyper* hp, float*
     if (!metrics_dev) metrics_dev = c->metrics_last != c->metrics ? c->metrics_last : nullptr;
     else if (c->metrics_last && metrics_dev != c->metrics_last)
         HIPCHK(hipMemcpyAsync(metrics_dev, c->metrics_last, SIGGAN_M_COUNT * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    const PhaseKey k = make_key(c, which == 1 ? 2 : 3, 0, false, false, hp, metrics_dev);
+    PhaseKey k = make_key(c, which == 1 ? 2 : 3, 0, false, false, hp, metrics_dev);
+    // One-launch update whenever the step count can live on the host: not under graph replay (arguments are baked into the
+    // captured launch) and not with the fp16 overflow guard (a skipped update leaves the device-side count behind).  The count
+    // is read back once after siggan_bind / siggan_params_changed and tracked from then on.
+    const int wi = which == 1 ? 1 : 0;
+    if ((c->mode & SIGGAN_MODE_GRAPH) == 0 && c->dt != DT_F16) {
+        if (!c->adam_t_known[wi]) {
+            float t0 = 0.f;
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMemcpy(&t0, which == 1 ? c->st.d_adam_steps : c->st.g_adam_steps, sizeof t0, hipMemcpyDeviceToHost));
+            c->adam_t[wi] = (double)t0; c->adam_t_known[wi] = true;
+        }
+        k.fused_t = c->adam_t[wi] + 1.0;
+    } else {
+        c->adam_t_known[wi] = false;
+    }
     if ((rc = run_phase(c, k, s))) return rc;
+    if (k.fused_t > 0.0) c->adam_t[wi] = k.fused_t;
     if (which == 0) c->g_dirty = true; else c->d_dirty = true;
     c->pending = 0;
     return finish_metrics(c, metrics_dev, metrics_host, s);
@@ -1413,6 +1431,10 @@ extern "C" int siggan_debug_tensor(siggan_ctx* c, const char* name, int32_t idx,
     else if (!strcmp(name, "g_da") && gl) { *ptr = c->g_da[idx]; *cap = gsz(idx); }
     else if (!strcmp(name, "d_a") && dl) { *ptr = c->d_a[idx]; *cap = dsz(idx); }
     else if (!strcmp(name, "d_dv") && dl) { *ptr = c->d_dv[idx]; *cap = dsz(idx); }
+    else if (!strcmp(name, "d_a_g") && dl) {     // the Discriminator activations of the last G step (they may start at row B)
+        const int64_t H = c->S >> idx, off = (int64_t)c->g_r0 * H * H * c->dC[idx];
+        *ptr = c->d_a[idx] + (size_t)off * c->es; *cap = dsz(idx) - off;
+    }
     else if (!strcmp(name, "z")) { *ptr = c->z; *cap = Bm * c->latent; typed = false; }
     else if (!strcmp(name, "z_g")) { *ptr = c->z_g; *cap = Bm * c->latent; typed = false; }
     else if (!strcmp(name, "img")) { *ptr = c->img; *cap = Bm * SS; typed = false; }

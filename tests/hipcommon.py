@@ -49,12 +49,14 @@ def _nchw(t):
 
 def hip_signs_d(eng, size, batch, passes):
     """Sign decisions (activation > 0) the HIP path took in the Discriminator, per pass and
-    block, NCHW bool -- handed to the oracle's backward (oracle._ActWithGivenSign)."""
+    block, NCHW bool -- handed to the oracle's backward (oracle._ActWithGivenSign).  passes == 1: the Discriminator pass
+    of a G step (debug tensor 'd_a_g': wherever the library put those rows); 2: D(real), D(fake) of a D step."""
     out = []
+    name = "d_a_g" if passes == 1 else "d_a"
     for p in range(passes):
         for l, c in enumerate(list(O.D_CHAIN[size]), start=1):
             h = size >> l
-            a = eng.debug_tensor("d_a", l, (passes * batch, h, h, c))[p * batch:(p + 1) * batch]
+            a = eng.debug_tensor(name, l, (passes * batch, h, h, c))[p * batch:(p + 1) * batch]
             out.append(_nchw(a) > 0)
     return out
 
