@@ -307,7 +307,7 @@ static void adam(mlpgan_ctx* c, int which, const siggan_hyper* hp, float* mt, hi
     const float gs = hp->grad_scale > 0.f ? hp->grad_scale : 1.0f;
     if (clip) launch_grad_sumsq(g, n, c->dev, c->partial, s);
     launch_adam_prepare(c->dev, steps, nt, hp->lr, hp->beta1, hp->beta2, gs, clip ? hp->clip_max_norm : 0.f,
-                        mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), s);
+                        mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), s, 0, nullptr, clip ? c->partial : nullptr);
     launch_adam(p, g, m, v, n, c->dev, hp->beta1, hp->beta2, hp->eps, (clip || gs != 1.0f) ? 1 : 0, s);
 }
 static int need_train_arenas(const mlpgan_ctx* c, int which) {

@@ -155,14 +155,16 @@ void launch_sn_sigma(const SnTable& t, int training, int slot, float eps, hipStr
 void launch_sn_combine(const SnTable& t, const float* g0, const float* g1, float* out, int64_t total, int npass, hipStream_t s);
 
 // ---- optimiser ------------------------------------------------------------------------------
-// reads steps[0], writes steps[i] += 1 for every tensor, derives the Adam scalars; with
-// clip_max_norm > 0 also needs the gradient norm (launch_grad_sumsq first)
+// launch_grad_sumsq: per-block partial sums of squares of the arena into `partial` (512 floats); whoever needs the norm adds
+// them itself in one fixed order (k_adam_prepare when handed `sumsq_partial`, every block of the fused k_adam): no finalize launch.
+// launch_adam_prepare: reads steps[0], writes steps[i] += 1 for every tensor, derives the Adam scalars; with clip_max_norm > 0
+// (or check_finite) it needs launch_grad_sumsq first and its `partial` as sumsq_partial
 void launch_grad_sumsq(const float* g, int64_t n, DevState* st, float* partial, hipStream_t s);
 // check_finite (fp16 chains; needs launch_grad_sumsq first): a non-finite sum of squares marks the update as skipped
 // (DevState::skip: k_adam returns at once, the step counts stay) and writes 1 to *metric_skipped, else 0
 void launch_adam_prepare(DevState* st, float* steps, int ntensors, double lr, double beta1, double beta2,
                          float grad_scale, float clip_max_norm, float* metric_norm, hipStream_t s,
-                         int check_finite = 0, float* metric_skipped = nullptr);
+                         int check_finite = 0, float* metric_skipped = nullptr, const float* sumsq_partial = nullptr);
 // beta^t for an integer-valued step count by repeated squaring in double: the SAME arithmetic on the host (fused path below)
 // and on the device (k_adam_prepare), so the two paths give bit-identical bias corrections (within an ulp of libm's pow,
 // which torch's Python-side `beta ** step` uses)
@@ -177,7 +179,7 @@ __host__ __device__ inline double pow_step(double b, double t) {
 // writes steps[0..ntensors) = t, ticks the RNG epoch and stores the pre-clip norm.  Same update arithmetic as launch_adam.
 void launch_adam_fused(float* p, float* g, float* m, float* v, int64_t n, DevState* st, float* steps, int ntensors, double t,
                        double lr, double beta1, double beta2, double eps, float grad_scale, float clip_max_norm,
-                       float* metric_norm, hipStream_t s);
+                       float* metric_norm, const float* sumsq_partial, hipStream_t s);
 void launch_adam(float* p, float* g, float* m, float* v, int64_t n, const DevState* st, double beta1,
                  double beta2, double eps, int write_back_grad, hipStream_t s);
 

@@ -774,9 +774,10 @@ __global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ par
 }
 // rows per strip of k_final_bwd_reduce: 4 (8-row strips need 256 registers and measured 36 vs 26 us)
 constexpr int FINAL_RY = 4;
+// two workgroups of this kernel per CU (188-204 registers): 512 of them walk the strips, each requesting strip i+1's rows while
+// it reduces strip i (26.5 -> 23.0 us at batch 64; 1024 blocks x 2 strips: 26.5; one strip per block: slower still)
 static int final_reduce_rows(int B, int S) {
-    const int cap = exp_knob("SIGGAN_X_FINAL_ROWS", 1024);
-    const int n = B * (S / FINAL_RY) * (S / 32); return n < cap ? n : cap;
+    const int n = B * (S / FINAL_RY) * (S / 32); return n < 512 ? n : 512;
 }
 void launch_final_bwd_reduce(int dt, const float* dpre, const float* W, const void* y, int B, int S, int C, const float* bn,
                              float* partial, float* partial_w, hipStream_t s) {
@@ -863,13 +864,11 @@ void launch_conv1_fwd(int dt, const float* x0, int n0, const float* x1, const fl
 // dW[co][kh][kw] = sum dv[n][oh][ow][co] * x[n][2oh-1+kh][2ow-1+kw];  db[co] = sum dv.
 // Same thread map as the forward; 17 x 4 sums per thread, folded over the 16 pixel lanes at the end
 // (shuffles, then LDS across the waves); partial row = [C*16 weights (co*16 + tap)] [C biases].
-// UP: every load of a strip is issued before the first FMA (PT float4 per thread in flight instead of 4: one round of memory
-// latency per strip instead of PT / 4)
-template <class T, int RY, int PT, bool UP>
+template <class T>
 __global__ __launch_bounds__(256) void k_conv1_wgrad(const T* __restrict__ dv, const float* __restrict__ x0, int n0,
                                                      const float* __restrict__ x1, float* __restrict__ partial, int S,
                                                      int nstrips) {
-    constexpr int C = 64;
+    constexpr int RY = 8, C = 64;
     __shared__ float sx[(2 * RY + 2) * 130];
     __shared__ float sh[4][16][69];
     const int Ho = S >> 1, nby = Ho / RY, Wp = S + 2;
@@ -883,25 +882,6 @@ __global__ __launch_bounds__(256) void k_conv1_wgrad(const T* __restrict__ dv, c
         stage_x<RY>(sx, seg_ptr(x0, n0, x1, n, S), oh0, S);
         __syncthreads();
         const T* gbase = dv + ((size_t)n * Ho + oh0) * Ho * C + q * 4;
-        if (UP) {                                       // (PT = RY * Ho / 16 pixels per thread, compile-time)
-            f4v g[PT];
-#pragma unroll
-            for (int u = 0; u < PT; ++u) g[u] = ld4<T>(gbase + (size_t)(pl + 16 * u) * C);
-#pragma unroll
-            for (int u = 0; u < PT; ++u) {
-                const int p = pl + 16 * u, r = p / Ho, ow = p - r * Ho;
-                const float* xr = sx + (2 * r) * Wp + 2 * ow;
-                acc[16] += g[u];
-#pragma unroll
-                for (int kh = 0; kh < 4; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 4; ++kw) {
-                        const float xv = xr[kh * Wp + kw];
-                        f4v& a = acc[kh * 4 + kw];
-                        a.x = fmaf(g[u].x, xv, a.x); a.y = fmaf(g[u].y, xv, a.y); a.z = fmaf(g[u].z, xv, a.z); a.w = fmaf(g[u].w, xv, a.w);
-                    }
-            }
-        } else
         for (int p0 = pl; p0 < RY * Ho; p0 += 64) {
             f4v g[4];
 #pragma unroll
@@ -949,11 +929,8 @@ void launch_conv1_wgrad(int dt, const void* dv, const float* x0, int n0, const f
                         int B, int S, int C, hipStream_t s) {
     const int nstrips = B * (S / 2 / 8);
     const int nch = nstrips < 1024 ? nstrips : 1024;
-    const bool up = S == 64 && exp_knob("SIGGAN_X_C1W_UP", 0) != 0;     // 8 rows x 32 columns / 16 pixel lanes = 16 float4 per thread
-    SIGGAN_DT_SWITCH(dt, T, {
-        if (up) hipLaunchKernelGGL((k_conv1_wgrad<T, 8, 16, true>), dim3(nch), dim3(256), 0, s, (const T*)dv, x0, n0, x1, partial, S, nstrips);
-        else hipLaunchKernelGGL((k_conv1_wgrad<T, 8, 16, false>), dim3(nch), dim3(256), 0, s, (const T*)dv, x0, n0, x1, partial, S, nstrips);
-    });
+    // (all 16 loads of a strip issued up front instead of four at a time measured slower: 16.1 vs 13.1 us)
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_conv1_wgrad<T>, dim3(nch), dim3(256), 0, s, (const T*)dv, x0, n0, x1, partial, S, nstrips));
     hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 17, 64)), dim3(1024), 0, s, partial, nch, C * 17, dW, C * 16, db);
 }
 
@@ -1024,10 +1001,8 @@ void launch_conv1_dgrad_tanh(int dt, const void* dv, const float* W, const float
     (void)C;
     const int Ho = S / 2;
     SIGGAN_DT_SWITCH(dt, T, {
-        if (exp_knob("SIGGAN_X_C1D_RA", 2) == 2)
-            hipLaunchKernelGGL((k_conv1_dgrad_tanh<T, 2>), dim3(B * (Ho / 2) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, W, img, dpre, S);
-        else
-            hipLaunchKernelGGL((k_conv1_dgrad_tanh<T, 4>), dim3(B * (Ho / 4) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, W, img, dpre, S);
+        // two block rows per thread: 118 registers, four waves per SIMD (four rows: 142 / three; 13.2 -> 12.0 us)
+        hipLaunchKernelGGL((k_conv1_dgrad_tanh<T, 2>), dim3(B * (Ho / 2) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, W, img, dpre, S);
     });
 }
 
@@ -1238,22 +1213,30 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int6
     const float s = block_sum(acc, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
-__global__ __launch_bounds__(256) void k_sumsq_fin(const float* __restrict__ partial, int nb, DevState* st) {
-    __shared__ float sh[4];
+// Sum of the nb (<= 512) block partials of k_sumsq by ONE wave in a fixed order (lane l adds partial[l], partial[l + 64], ...,
+// then a butterfly): the consumers of the norm do this themselves -- k_adam_prepare, or wave 0 of every k_adam<FUSED> block --
+// so no finalize kernel sits between k_sumsq and the optimiser, and both paths form bit-identical sums.
+__device__ __forceinline__ float sum_partials_wave(const float* __restrict__ partial, int nb, int lane) {
     float acc = 0.f;
-    for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
-    const float s = block_sum(acc, sh);
-    if (threadIdx.x == 0) st->sumsq = s;
+    for (int i = lane; i < nb; i += 64) acc += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    return acc;
 }
+static constexpr int SUMSQ_BLOCKS = 512;
 void launch_grad_sumsq(const float* g, int64_t n, DevState* st, float* partial, hipStream_t s) {
-    const int nb = 512;
-    hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, s, g, n, partial);
-    hipLaunchKernelGGL(k_sumsq_fin, dim3(1), dim3(256), 0, s, partial, nb, st);
+    (void)st;
+    hipLaunchKernelGGL(k_sumsq, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, g, n, partial);
 }
 
 __global__ void k_adam_prepare(DevState* st, float* __restrict__ steps, int ntensors, double lr, double beta1, double beta2,
                                float grad_scale, float clip_max_norm, float* __restrict__ metric_norm, int check_finite,
-                               float* __restrict__ metric_skipped) {
+                               float* __restrict__ metric_skipped, const float* __restrict__ sumsq_partial) {
+    if (sumsq_partial) {                                               // (one wave: blockDim.x == 64)
+        const float ssq = sum_partials_wave(sumsq_partial, SUMSQ_BLOCKS, threadIdx.x);
+        if (threadIdx.x == 0) st->sumsq = ssq;
+        __syncthreads();
+    }
     // fp16 chains carry a static gradient scale: an activation gradient that overflowed arrives here as inf / NaN in the sum
     // of squares -- the update is skipped (parameters, moments, step counts untouched) instead of poisoning the fp32 masters
     const bool skip = check_finite && !isfinite(st->sumsq);
@@ -1280,9 +1263,10 @@ __global__ void k_adam_prepare(DevState* st, float* __restrict__ steps, int nten
     st->grad_mul = mul;
 }
 void launch_adam_prepare(DevState* st, float* steps, int ntensors, double lr, double beta1, double beta2, float grad_scale,
-                         float clip_max_norm, float* metric_norm, hipStream_t s, int check_finite, float* metric_skipped) {
+                         float clip_max_norm, float* metric_norm, hipStream_t s, int check_finite, float* metric_skipped,
+                         const float* sumsq_partial) {
     hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, s, st, steps, ntensors, lr, beta1, beta2, grad_scale,
-                       clip_max_norm, metric_norm, check_finite, metric_skipped);
+                       clip_max_norm, metric_norm, check_finite, metric_skipped, sumsq_partial);
 }
 
 struct AdamHost {          // scalars of a fused update, formed on the host (FUSED: no k_adam_prepare ran)
@@ -1290,6 +1274,7 @@ struct AdamHost {          // scalars of a fused update, formed on the host (FUS
     int ntensors;
     float* steps;
     float* metric_norm;
+    const float* sumsq_partial;   // k_sumsq's block partials (clip): every block's wave 0 adds them itself
 };
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
@@ -1303,7 +1288,13 @@ __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __
         mul = h.grad_scale; ss = -h.step_size; bc2 = h.bc2_sqrt;
         float norm = 0.f;
         if (h.clip_max_norm > 0.f) {                                   // nn.utils.clip_grad_norm_ (norm_type 2), k_adam_prepare's expression
-            norm = sqrtf(st->sumsq) * h.grad_scale;
+            __shared__ float s_ssq;
+            if (threadIdx.x < 64) {
+                const float ssq = sum_partials_wave(h.sumsq_partial, SUMSQ_BLOCKS, threadIdx.x);
+                if (threadIdx.x == 0) s_ssq = ssq;
+            }
+            __syncthreads();
+            norm = sqrtf(s_ssq) * h.grad_scale;
             mul = h.grad_scale * fminf(h.clip_max_norm / (norm + 1e-6f), 1.0f);
         }
         if (blockIdx.x == 0) {                                         // what k_adam_prepare does besides the scalars
@@ -1345,14 +1336,14 @@ __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __
 }
 void launch_adam_fused(float* p, float* g, float* m, float* v, int64_t n, DevState* st, float* steps, int ntensors, double t,
                        double lr, double beta1, double beta2, double eps, float grad_scale, float clip_max_norm,
-                       float* metric_norm, hipStream_t s) {
+                       float* metric_norm, const float* sumsq_partial, hipStream_t s) {
     const int64_t n4 = n / 4;
     const int tail = (int)(n - n4 * 4);
     AdamHost h;
     h.step_size = (float)(lr / (1.0 - pow_step(beta1, t)));            // torch.optim.Adam: lr / (1 - beta1**step), in double
     h.bc2_sqrt = (float)sqrt(1.0 - pow_step(beta2, t));
     h.grad_scale = grad_scale; h.clip_max_norm = clip_max_norm; h.t = (float)t; h.ntensors = ntensors; h.steps = steps;
-    h.metric_norm = metric_norm;
+    h.metric_norm = metric_norm; h.sumsq_partial = sumsq_partial;
     const int wb = (clip_max_norm > 0.f || grad_scale != 1.0f) ? 1 : 0;
     hipLaunchKernelGGL(k_adam<true>, dim3(cdiv(n4 + tail, 256)), dim3(256), 0, s, (float4*)p, (float4*)g, (float4*)m, (float4*)v,
                        n4, p + n4 * 4, g + n4 * 4, m + n4 * 4, v + n4 * 4, tail, st, (float)(1.0 - beta1), (float)beta2,
