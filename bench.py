@@ -344,7 +344,7 @@ def main(argv=None):
         gbps = top["bytes"] / (top["ms"] * 1e-3) / 1e9
         traffic, traffic_src, step_bytes = None, None, None   # HBM bytes from the committed PMC passes (separate rocprofv3 runs)
         tag = "" if (dtype, size, batch) == ("f32", 64, 64) else f"_{dtype}_s{size}_b{batch}"
-        tfile = os.path.join("profiles", f"r02_pmc_traffic{tag}.json")
+        tfile = os.path.join("profiles", f"r03_pmc_traffic{tag}.json")
         try:
             with open(os.path.join(ROOT, tfile)) as f:
                 tj = json.load(f)

@@ -149,7 +149,7 @@ struct siggan_ctx {
     // (element type dt: fc_y, g_y, g_a, g_da, d_a, d_dv and the MFMA weight packs g_up, g_dn, d_dn, d_up; fp32: the rest)
     float *z, *g_bn[MAXL + 1], *g_bne[MAXL + 1];
     char *fc_y, *g_y[MAXL + 1], *g_a[MAXL + 1], *g_da[MAXL + 1];
-    char *g_ae[MAXL + 1];     // (experiment) activations of the EVAL-mode Generator forward when it runs beside the training forward
+    char *g_ae[MAXL + 1];     // 16-bit contexts: activations of the EVAL-mode Generator forward (it runs beside the training forward)
     float *img, *dpre;
     char *d_a[MAXL + 1], *d_dv[MAXL + 1];
     float *d_noise[MAXL + 1];
@@ -292,7 +292,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
             const int64_t H = 4 << l, n = Bm * H * H * c->gC[l];
             if (l == 0) c->g_y[0] = c->fc_y; else carve_t(&c->g_y[l], n);
             carve_t(&c->g_a[l], n);
-            carve_t(&c->g_ae[l], n);
+            if (c->dt != DT_F32) carve_t(&c->g_ae[l], n); else if (pass == 1) c->g_ae[l] = c->g_a[l];
             carve_t(&c->g_da[l], n);
             carve(&c->g_bn[l], 6 * (int64_t)(l == 0 ? c->F : c->gC[l]));
             carve(&c->g_bne[l], 4 * (int64_t)(l == 0 ? c->F : c->gC[l]));   // eval-mode [scale|shift|mean|rstd]
@@ -319,7 +319,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->slab, c->slab_floats);
         carve(&c->slab_k, c->slab_k_floats);
         carve(&c->slab_k2, c->slab_k_floats);
-        carve(&c->slab_k3, c->slab_k_floats);
+        if (c->dt != DT_F32) carve(&c->slab_k3, c->slab_k_floats); else if (pass == 1) c->slab_k3 = c->slab_k2;
         carve(&c->partial, (int64_t)2 << 20);
         carve(&c->partial_b, (int64_t)2 << 20);
         carve(&c->partial_c, (int64_t)2 << 20);
@@ -605,7 +605,7 @@ static GConvArgs gconv_args(siggan_ctx* c) {
 static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s,
                            float* partial = nullptr, float* slab_k = nullptr, uint32_t rng_sid = 0, float* z_out = nullptr) {
     if (!partial) partial = c->partial;
-    char* const* const A = (!training && exp_knob("SIGGAN_X_EARLY_GFWD", 0)) ? c->g_ae : c->g_a;
+    char* const* const A = training ? c->g_a : c->g_ae;     // (fp32: the same buffers)
     // fc + BatchNorm1d + ReLU: one MFMA launch (fc.hip) whenever the shape allows, else the generic kernels
     if (c->fc_fused && launch_fc_fwd_fused(c->dt, z, GP(c, gi_fc_w()), GP(c, gi_fc_b()), c->fc_y, A[0], GP(c, gi_bn0_w()),
                                           GP(c, gi_bn0_b()), c->st.g_bn_running_mean, c->st.g_bn_running_var, c->st.g_bn_batches,
@@ -853,9 +853,12 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     if (k.pre_real != 2) d_forward_rows(c, c->real_stage, 0, B, drop, L.a, c->slab_k2);
     const float* fake = c->img;
     const bool spec_fwd = k.spec_g && k.variant != SIGGAN_STEP_ABLATION;
-    // (experiment SIGGAN_X_EARLY_GFWD: the training forward starts beside the eval forward -- own activation buffers -- but
-    // is ENQUEUED behind it, so that the critical lane's kernels reach the dispatcher first)
-    const bool spec_early = spec_fwd && exp_knob("SIGGAN_X_EARLY_GFWD", 0) != 0;
+    // siggan_step_begin: the G step's training forward depends on nothing the D step changes.  16-bit contexts (every kernel
+    // is a few microseconds: the step is a chain of launch latencies) start it HERE, beside the eval forward, with the eval
+    // forward's activations in buffers of their own: bf16 batch 64 0.747 -> 0.723 ms.  fp32 keeps it behind D(fake) (below):
+    // there the early start measured 0.7 % slower -- its BatchNorm / fc kernels take matrix-pipe time from the eval forward,
+    // which is on the step's critical lane.
+    const bool spec_early = spec_fwd && c->dt != DT_F32;
     hipEvent_t e_early = nullptr;
     if (spec_early) { e_early = L.next(); L.record(e_early, L.m); }
     if (k.variant == SIGGAN_STEP_ABLATION) {
@@ -868,23 +871,20 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     } else {
         g_forward_pass(c, k.has_z ? c->z : nullptr, B, false, c->img, L.m, nullptr, nullptr, 1, c->z);   // G.eval(), no grad (train...py:314-315)
     }
-    auto early_fwd = [&]() {
+    if (spec_early) {       // (enqueued behind the eval forward: the critical lane's kernels reach the dispatcher first)
         L.wait(c->s_c, e_early);
         g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k3, 2, c->z_g);
         L.record(c->ev_gfwd, c->s_c);
-    };
-    if (spec_early && exp_knob("SIGGAN_X_EARLY_GFWD", 0) == 1) early_fwd();
+    }
     L.join(L.a);
     // siggan_step_begin: the G step's training forward depends on nothing the D step changes, so it
     // runs on its own lane beside D(fake) and the D step's backward (after the eval forward above: it
     // moves the BatchNorm running statistics and reuses the activation buffers; its own image / z /
     // scratch).  It forks HERE but is enqueued after D(fake), whose kernels the dispatcher should see first.
-    // (starting it earlier still, beside the eval forward with activation buffers of its own, measured 0.8 % slower: DESIGN 4)
     hipEvent_t e_spec = nullptr;
     if (spec_fwd && !spec_early) { e_spec = L.next(); L.record(e_spec, L.m); }
     d_forward_rows(c, fake, B, B, drop, L.m, c->slab_k);             // D(fake) into rows [B, 2B)
     if (k.pre_real == 2) L.wait(L.m, c->ev_dreal);
-    if (spec_early && exp_knob("SIGGAN_X_EARLY_GFWD", 0) == 2) early_fwd();     // (gated early, enqueued behind D(fake))
     if (spec_fwd && !spec_early) {
         L.wait(c->s_c, e_spec);
         g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2, 2, c->z_g);
