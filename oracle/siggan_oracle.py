@@ -408,7 +408,7 @@ def sn_weights(d_sd, sn: Dict[str, Tensor], size: int, training: bool) -> Dict[s
 
 
 def d_step_sn(g_sd, d_sd, sn, d_opt: AdamState, real, z, masks_real, masks_fake, size,
-              lr=2e-4, beta1=0.5, beta2=0.999, label_smoothing=0.9, dropout: float = 0.25):
+              lr=2e-4, beta1=0.5, beta2=0.999, label_smoothing=0.9, dropout: float = 0.25, signs=None, record=None):
     """train_discriminator_step with Discriminator(use_spectral_norm=True) (vanilla_gan_model.py:180-252): D.train(), so the real
     and the fake forward each run a power iteration and see different effective weights; the gradient w.r.t. weight_orig goes
     through both sigmas."""
@@ -416,8 +416,10 @@ def d_step_sn(g_sd, d_sd, sn, d_opt: AdamState, real, z, masks_real, masks_fake,
     leaf = _leafs(d_sd, names)
     with torch.no_grad():
         fake = g_forward(g_sd, z, training=False, size=size)
-    real_preds = d_forward(sn_weights(leaf, sn, size, True), real, size, masks_real, dropout)
-    fake_preds = d_forward(sn_weights(leaf, sn, size, True), fake, size, masks_fake, dropout)
+    nb = len(D_CHAIN[size])
+    s_real, s_fake = (None, None) if signs is None else (signs[:nb], signs[nb:])       # D(real) blocks, then D(fake) blocks
+    real_preds = d_forward(sn_weights(leaf, sn, size, True), real, size, masks_real, dropout, signs=s_real, record=record)
+    fake_preds = d_forward(sn_weights(leaf, sn, size, True), fake, size, masks_fake, dropout, signs=s_fake, record=record)
     loss_real, loss_fake = bce(real_preds, label_smoothing), bce(fake_preds, 0.0)
     loss = loss_real + loss_fake
     gl = torch.autograd.grad(loss, [leaf[k] for k in names])
@@ -428,17 +430,19 @@ def d_step_sn(g_sd, d_sd, sn, d_opt: AdamState, real, z, masks_real, masks_fake,
     return metrics, grads
 
 
-def g_step_sn(g_sd, d_sd, sn, g_opt: AdamState, z, size, lr=2e-4, beta1=0.5, beta2=0.999):
+def g_step_sn(g_sd, d_sd, sn, g_opt: AdamState, z, size, lr=2e-4, beta1=0.5, beta2=0.999, signs=None, record=None):
     """train_generator_step against a spectral-norm Discriminator (vanilla_gan_model.py:254-306): D.eval() -- no power
     iteration, sigma from the stored (u, v)."""
     names = param_names(g_state_specs(z.shape[1], size))
     leaf = dict(g_sd)
     leaf.update(_leafs(g_sd, names))
-    fake = g_forward(leaf, z, training=True, size=size)
+    ng = len(G_CHAIN[size])
+    s_g, s_d = (None, None) if signs is None else (signs[:ng], signs[ng:])             # fc, G blocks, then D blocks
+    fake = g_forward(leaf, z, training=True, size=size, signs=s_g, record=record)
     for k in g_sd:
         if k not in names:
             g_sd[k] = leaf[k]
-    fake_preds = d_forward(sn_weights(d_sd, sn, size, False), fake, size, None)
+    fake_preds = d_forward(sn_weights(d_sd, sn, size, False), fake, size, None, signs=s_d, record=record)
     loss = bce(fake_preds, 1.0)
     gl = torch.autograd.grad(loss, [leaf[k] for k in names])
     grads = {k: g.detach() for k, g in zip(names, gl)}
@@ -447,29 +451,35 @@ def g_step_sn(g_sd, d_sd, sn, g_opt: AdamState, z, size, lr=2e-4, beta1=0.5, bet
 
 
 def ablation_step(g_sd, d_sd, g_opt: AdamState, d_opt: AdamState, real, z, masks_real, masks_fake, masks_g, size,
-                  lr_g=2e-4, lr_d=2e-4, beta1=0.5, beta2=0.999, label_smoothing=0.9, dropout: float = 0.25, q=None):
+                  lr_g=2e-4, lr_d=2e-4, beta1=0.5, beta2=0.999, label_smoothing=0.9, dropout: float = 0.25, q=None,
+                  signs=None, record=None):
     """One iteration of AblationGANTrainer.train_epoch (ablation_vanilla_gan_signatures.py:397-467), for the standard
     (ReLU) Generator: both networks in train mode for the whole iteration; ONE Generator forward (BatchNorm batch
     statistics, running stats updated) whose detached image feeds the D update (:414-430) and through which the G update
     back-propagates (:432-441); the G update runs the UPDATED Discriminator, still in train mode (a third set of dropout
-    masks), against the smoothed real label.  Returns (metrics, d_grads, g_grads)."""
+    masks), against the smoothed real label.  Returns (metrics, d_grads, g_grads).
+    ``signs`` / ``record`` (see _act): dicts keyed 'g' (fc + Generator blocks), 'd_real', 'd_fake', 'd_g' (the Discriminator
+    pass of the G update), each a per-layer list -- the harness calls D(real) BEFORE the Generator, this restatement after it,
+    so the groups are named rather than positional."""
     g_names = param_names(g_state_specs(z.shape[1], size))
     d_names = param_names(d_state_specs(size, real.shape[1]))
     g_leaf = dict(g_sd)
     g_leaf.update(_leafs(g_sd, g_names))
-    fake = g_forward(g_leaf, z, training=True, size=size, q=q)
+    sg = (lambda key: None) if signs is None else (lambda key: signs[key])
+    rc = (lambda key: None) if record is None else (lambda key: record.setdefault(key, []))
+    fake = g_forward(g_leaf, z, training=True, size=size, q=q, signs=sg("g"), record=rc("g"))
     for k in g_sd:
         if k not in g_names:
             g_sd[k] = g_leaf[k]
     d_leaf = _leafs(d_sd, d_names)
-    real_preds = d_forward(d_leaf, real, size, masks_real, dropout, q=q)
-    fake_preds = d_forward(d_leaf, fake.detach(), size, masks_fake, dropout, q=q)
+    real_preds = d_forward(d_leaf, real, size, masks_real, dropout, q=q, signs=sg("d_real"), record=rc("d_real"))
+    fake_preds = d_forward(d_leaf, fake.detach(), size, masks_fake, dropout, q=q, signs=sg("d_fake"), record=rc("d_fake"))
     loss_real, loss_fake = bce(real_preds, label_smoothing), bce(fake_preds, 0.0)
     d_loss = loss_real + loss_fake
     gl = torch.autograd.grad(d_loss, [d_leaf[k] for k in d_names])
     d_grads = {k: g.detach() for k, g in zip(d_names, gl)}
     d_opt.apply(d_sd, d_grads, lr_d, beta1, beta2)
-    preds_g = d_forward(d_sd, fake, size, masks_g, dropout, q=q)            # the updated D, dropout still active
+    preds_g = d_forward(d_sd, fake, size, masks_g, dropout, q=q, signs=sg("d_g"), record=rc("d_g"))   # the updated D, dropout still active
     g_loss = bce(preds_g, label_smoothing)
     gl = torch.autograd.grad(g_loss, [g_leaf[k] for k in g_names])
     g_grads = {k: g.detach() for k, g in zip(g_names, gl)}

@@ -64,6 +64,13 @@ def census_signs(f, step):
     return out
 
 
+def ablation_groups(size, items):
+    """Split a per-layer list in the ablation harness' CALL order -- D(real) blocks, Generator (fc + blocks), D(fake.detach())
+    blocks, D(fake) blocks of the G update -- into the named groups oracle.ablation_step takes."""
+    nb, ng = len(O.D_CHAIN[size]), len(O.G_CHAIN[size])
+    return {"d_real": items[:nb], "g": items[nb:nb + ng], "d_fake": items[nb + ng:2 * nb + ng], "d_g": items[2 * nb + ng:]}
+
+
 def flips_vs_census(f, step, signs, keep=None):
     """Decisions of another implementation (``signs``: full bool tensors per activation layer, NCHW order) that differ from the
     reference run's on the census elements: list of (layer, flat index, the reference's value / layer max).  ``keep``: per

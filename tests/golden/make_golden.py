@@ -367,14 +367,19 @@ def make_spectral_norm_steps():
         tag = f"s{size}_b{B}"
         m = model()
         tap = MaskTap(m.discriminator)
+        acts = ActTap(m.discriminator)                      # D(real) blocks, then D(fake) blocks
         torch.manual_seed(SEED_TORCH + 7)
         met = m.train_discriminator_step(real, noise=z)
-        tap.close()
+        tap.close(); acts.close()
+        acts.store(f"{tag}/d", out)
         out[f"{tag}/masks"] = I.pack_masks(tap.masks)
         record_step(f"{tag}/d", m, m.discriminator, m.d_optimizer, met, out, extra_buffers=True)
         # the G step follows on the SAME model: with D.eval() no power iteration runs, and the un-iterated random (u, v) of a
         # fresh state would give a sigma far from the spectral norm (saturated predictions, zero gradients)
+        acts = ActTap(m.generator, m.discriminator)         # fc, G blocks, then D blocks
         met = m.train_generator_step(B, noise=z2)
+        acts.close()
+        acts.store(f"{tag}/g", out)
         record_step(f"{tag}/g", m, m.generator, m.g_optimizer, met, out, extra_buffers=True)
         probes(f"{tag}/g/dbuf", {k: v.float() for k, v in m.discriminator.state_dict().items() if k.endswith(("_u", "_v"))}, out)
     out["meta"] = np.array(json.dumps({"torch": torch.__version__, "threads": torch.get_num_threads(),
@@ -398,6 +403,9 @@ def make_ablation_step():
         ls = 0.9
         G.train(); D.train()                                               # :403-404
         tap = MaskTap(D)
+        # census in the harness' CALL order: D(real) blocks, Generator (fc + blocks), D(fake.detach()) blocks, D(fake) blocks of
+        # the G update (hooks on D first, then G: ActTap appends per call, not per module)
+        acts = ActTap(D, G)
         torch.manual_seed(SEED_TORCH + 5)
         real_labels, fake_labels = torch.full((B, 1), ls), torch.zeros(B, 1)   # :419-420
         m.d_optimizer.zero_grad()                                           # :423
@@ -418,7 +426,8 @@ def make_ablation_step():
         g_loss = crit(d_output_for_g, real_labels)                          # :443
         g_loss.backward()
         m.g_optimizer.step()                                                # :446
-        tap.close()
+        tap.close(); acts.close()
+        acts.store(f"{tag}", out)
         record_step(f"{tag}/g", m, G, m.g_optimizer, {"g_loss": g_loss.item(), "g_fake_mean": d_output_for_g.mean().item()},
                     out, extra_buffers=True)
         nb = 4 if size == 64 else 5

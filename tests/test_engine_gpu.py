@@ -419,13 +419,40 @@ def test_rng_position_survives_a_larger_batch_and_is_readable():
     eng.close()
 
 
+def _rel_grads(eng, which, o_grads, ref_gn):
+    """worst gradient error of the HIP path against an oracle run, relative to the tensor's scale (floored as in _scales)"""
+    gv = eng.views(which, "grads")
+    scale, _ = _scales(o_grads, list(gv), ref_gn)
+    return max(float((gv[k].cpu() - o_grads[k]).abs().max()) / scale[k] for k in gv), scale
+
+
+def _weights_in_envelope(eng, which, o_grads, scale, init_sd, init_opt, tol, step, what):
+    """every weight inside what one torch-Adam update gives for a gradient within tol of the oracle's (see _adam_envelope)"""
+    wv = eng.views(which, "params")
+    for k in wv:
+        lo, hi = _adam_envelope(init_sd[k], init_opt.m[k], init_opt.v[k], o_grads[k], tol * scale[k], step)
+        w = wv[k].cpu()
+        assert bool(((w >= lo) & (w <= hi)).all()), f"{what} weight {k} outside the Adam envelope"
+
+
+def _golden_rel(f, tag, grads, names, scale, ren=lambda k: k):
+    """worst deviation of a run's gradients from the reference's record: probes / tensor scale and relative norms"""
+    gn = f[f"{tag}/grad_norm"]
+    live = gn > 1e-5 * float(gn.max())
+    dn = max(abs(float(grads[k].norm()) - float(r)) / float(r) for k, r, lv in zip(names, gn, live) if lv)
+    dp = max(float(np.abs(probe(grads[k], ren(k)) - f[f"{tag}/grad/{ren(k)}"]).max()) / scale[k] for k in names)
+    return max(dn, dp)
+
+
 @pytest.mark.parametrize("size,latent,batch", [(64, 100, 8), (128, 128, 4)])
 def test_ablation_step_variant(size, latent, batch):
     """siggan_set_step_variant(SIGGAN_STEP_ABLATION): AblationGANTrainer.train_epoch's iteration
     (ablation_vanilla_gan_signatures.py:397-467) -- both nets in train mode, one shared Generator forward, G target = smoothed
-    label, three dropout mask sets -- against the oracle and against the fixture replayed on the reference's own modules."""
+    label, three dropout mask sets.  Same chain as test_single_steps: HIP vs the oracle given the HIP path's activation-sign
+    decisions (arithmetic), the oracle given the REFERENCE replay's decisions (fixture census) vs the fixture, and the HIP
+    decisions that differ from the replay's counted against the census."""
     import os
-    from common import GOLDEN
+    from common import GOLDEN, ablation_groups
     from hipcommon import cuda, make_engine
     f = np.load(os.path.join(GOLDEN, "golden_ablation_step.npz"))
     tag = f"s{size}_b{batch}"
@@ -435,27 +462,60 @@ def test_ablation_step_variant(size, latent, batch):
     real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
     eng = make_engine(size, latent, batch, warm=True)
     eng.set_step_variant("ablation")
-    met = eng.ablation_step(cuda(real), cuda(z), masks)
-    g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=True)
-    o_met, o_dg, o_gg = O.ablation_step(g_sd, d_sd, g_opt, d_opt, real, z, masks[:nb], masks[nb:2 * nb], masks[2 * nb:], size)
+    # the iteration phase by phase (what Engine.ablation_step does), reading the sign decisions where they still stand
+    eng.d_compute_grads(cuda(real), cuda(z), masks, 0.9, mask_passes=3)
+    s_g, s_d = hip_signs_g(eng, size, batch), hip_signs_d(eng, size, batch, 2)
+    d_grads_hip = {k: v.cpu().clone() for k, v in eng.views("d", "grads").items()}
+    met = eng.d_apply()
+    eng.g_compute_grads(batch, label_smoothing=0.9)
+    s_dg = hip_signs_d(eng, size, batch, 1)
+    met.update(eng.g_apply())
+    hip = {"g": s_g, "d_real": s_d[:nb], "d_fake": s_d[nb:], "d_g": s_dg}
+    keep = {"g": None, "d_real": masks[:nb], "d_fake": masks[nb:2 * nb], "d_g": masks[2 * nb:]}
+
+    def run(signs, rec):
+        g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=True)
+        o = O.ablation_step(g_sd, d_sd, g_opt, d_opt, real, z, masks[:nb], masks[nb:2 * nb], masks[2 * nb:], size, signs=signs, record=rec)
+        return o, g_sd, d_sd, g_opt, d_opt
+    rec = {}
+    (o_met, o_dg, o_gg), g_sd, d_sd, g_opt, d_opt = run(hip, rec)
+    for grp in ("g", "d_real", "d_fake", "d_g"):
+        count_sign_flips(hip[grp], rec[grp], keep=keep[grp])           # every disagreement within 1e-5 of the layer scale of zero
     for k, v in o_met.items():
         assert_close(met[k], v, 2e-4, 2e-6, f"ablation metric {k} vs oracle")
         key = f"{tag}/{k[0]}/metric/{k}"
         if key in f:
             assert_close(met[k], f[key], 2e-4, 2e-6, f"ablation metric {k} vs golden")
-    for which, og, osd, oopt in (("d", o_dg, d_sd, d_opt), ("g", o_gg, g_sd, g_opt)):
-        gv, mv, wv = eng.views(which, "grads"), eng.views(which, "exp_avg"), eng.views(which, "params")
-        gscale = max(float(t.abs().max()) for t in og.values())
-        ref_gn = f[f"{tag}/{which}/grad_norm"]
-        for (k, g), rn in zip(gv.items(), ref_gn):
-            noise = rn < 1e-5 * float(ref_gn.max())
-            scale = max(float(og[k].abs().max()), (1e-2 if noise else 1e-3) * gscale)
-            # (free-running oracle: a borderline activation sign may differ, bounded as in test_single_steps' golden branch)
-            assert float((g.cpu() - og[k]).abs().max()) <= 5e-3 * scale, (which, k)
-            assert_close(probe(g.cpu(), k), f[f"{tag}/{which}/grad/{k}"], 0, 5e-3 * scale, f"ablation grad {k} vs golden")
-            assert abs(float(g.norm()) - rn) <= 2e-3 * rn + 1e-4 * float(ref_gn.max()), (which, k, "norm vs golden")
-            assert float((mv[k].cpu() - oopt.m[k]).abs().max()) <= 5e-3 * scale, (which, k, "exp_avg")
-            assert float((wv[k].cpu() - osd[k]).abs().max()) <= 2.5 * 2e-4, (which, k, "weights")
+    row = {}
+    gv = eng.views("g", "grads")
+    sc_d, _ = _scales(o_dg, list(o_dg), f[f"{tag}/d/grad_norm"])
+    row["hip_vs_oracle_with_hip_signs_d"] = max(float((d_grads_hip[k] - o_dg[k]).abs().max()) / sc_d[k] for k in o_dg)
+    row["hip_vs_oracle_with_hip_signs_g"], sc_g = _rel_grads(eng, "g", o_gg, f[f"{tag}/g/grad_norm"])
+    assert row["hip_vs_oracle_with_hip_signs_d"] <= 2e-4 and row["hip_vs_oracle_with_hip_signs_g"] <= 1e-4, row      # measured: 5.7e-5 / 7.7e-6
+    i_g, i_d, i_gopt, i_dopt = oracle_states(size, latent, warm=True)
+    for which, og, oopt, sc, isd, iopt in (("d", o_dg, d_opt, sc_d, i_d, i_dopt), ("g", o_gg, g_opt, sc_g, i_g, i_gopt)):
+        mv = eng.views(which, "exp_avg")
+        for k in mv:
+            assert float((mv[k].cpu() - oopt.m[k]).abs().max()) <= 2e-4 * sc[k], (which, k, "exp_avg")
+        _weights_in_envelope(eng, which, og, sc, isd, iopt, 2e-4, oopt.step, f"ablation {which}")
+    # the reference replay's own decisions -> the fixture, on this host
+    census = census_signs(f, tag)
+    (c_met, c_dg, c_gg), *_ = run(ablation_groups(size, census), None)
+    row["oracle_with_reference_signs_vs_reference"] = max(_golden_rel(f, f"{tag}/d", c_dg, list(c_dg), sc_d), _golden_rel(f, f"{tag}/g", c_gg, list(c_gg), sc_g))
+    assert row["oracle_with_reference_signs_vs_reference"] <= 1e-4, row
+    order = hip["d_real"] + hip["g"] + hip["d_fake"] + hip["d_g"]              # the harness' call order = the census' order
+    flips = flips_vs_census(f, tag, order, keep=list(masks[:nb]) + [None] * len(hip["g"]) + list(masks[nb:]))
+    row["flips_vs_reference"] = len(flips)
+    row["hip_vs_reference"] = max(_golden_rel(f, f"{tag}/d", d_grads_hip, list(o_dg), sc_d),
+                                  _golden_rel(f, f"{tag}/g", {k: v.cpu() for k, v in gv.items()}, list(o_gg), sc_g))
+    pred = max(_golden_rel(f, f"{tag}/d", o_dg, list(o_dg), sc_d), _golden_rel(f, f"{tag}/g", o_gg, list(o_gg), sc_g))
+    row["predicted_by_the_flips"] = pred
+    if not flips:
+        assert row["hip_vs_reference"] <= 1e-3, row
+    else:
+        assert abs(row["hip_vs_reference"] - pred) <= 1e-3, row
+    MARGINS[f"ablation/{tag}"] = row
+    _dump_margins()
     for k, t in eng.bn_views().items():
         _scale_close(probe(t.float().cpu(), k), f[f"{tag}/g/buf/{k}"], f"ablation BN buffer {k} vs golden")
     # the trainer step must be unaffected once the variant is switched back
@@ -469,7 +529,9 @@ def test_ablation_step_variant(size, latent, batch):
 def test_spectral_norm_training(size, latent, batch):
     """Engine(spectral_norm=True): one D step then one G step (trainer variant) against the oracle's restatement of torch's
     spectral-norm hook and against VanillaGAN(use_spectral_norm=True) run on the reference itself -- power iteration per
-    training forward (different effective weights for the real and the fake pass), gradient through sigma, u / v buffers."""
+    training forward (different effective weights for the real and the fake pass), gradient through sigma, u / v buffers.
+    The oracle is given the HIP path's sign decisions (arithmetic) resp. the reference run's (fixture census), as in
+    test_single_steps; the G step runs on the state the D step left, in the engine and in both oracle runs."""
     import os
     from common import GOLDEN
     from hipcommon import cuda, load_engine_state
@@ -484,37 +546,72 @@ def test_spectral_norm_training(size, latent, batch):
     real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
     eng = load_engine_state(Engine(latent_dim=latent, image_size=size, max_batch=batch, device="cuda:0", spectral_norm=True),
                             size, latent, warm=True)
-    g_sd, d_sd, g_opt, d_opt, sn = _sn_states(size, latent)
+    _, _, _, _, sn0 = _sn_states(size, latent)
     for k, v in eng.sn_views().items():
-        v.copy_(sn[k])
+        v.copy_(sn0[k])
     ren = lambda k: k + "_orig" if k.endswith(".weight") else k
+    row = {}
 
-    def check(which, met, o_met, o_grads, o_sd, o_opt, step_tag, gtol):
-        for k, v in o_met.items():
-            assert_close(met[k], v, 2e-4, 2e-6, f"SN {which} metric {k} vs oracle")
-            assert_close(met[k], f[f"{step_tag}/metric/{k}"], 2e-4, 2e-6, f"SN {which} metric {k} vs golden")
-        gv, mv, wv = eng.views(which, "grads"), eng.views(which, "exp_avg"), eng.views(which, "params")
-        gscale = max(float(t.abs().max()) for t in o_grads.values())
-        for k, g in gv.items():
-            rk = ren(k) if which == "d" else k
-            scale = max(float(o_grads[k].abs().max()), 1e-3 * gscale)
-            assert float((g.cpu() - o_grads[k]).abs().max()) <= gtol * scale, (which, k, float((g.cpu() - o_grads[k]).abs().max()), scale)
-            assert_close(probe(g.cpu(), rk), f[f"{step_tag}/grad/{rk}"], 0, max(gtol, 1e-3) * scale, f"SN {which} grad {k} vs golden")
-            assert float((mv[k].cpu() - o_opt.m[k]).abs().max()) <= gtol * scale, (which, k, "exp_avg")
-            assert float((wv[k].cpu() - o_sd[k]).abs().max()) <= 2.5 * 2e-4, (which, k, "weights")
-
+    # ---- D step ----
     met = eng.d_step(cuda(real), cuda(z), masks)
-    o_met, o_grads = O.d_step_sn(g_sd, d_sd, sn, d_opt, real, z, masks[:nb], masks[nb:], size)
-    check("d", met, o_met, o_grads, d_sd, d_opt, f"{tag}/d", 5e-3)
-    for k, v in eng.sn_views().items():                       # two power iterations later
-        _scale_close(v.cpu().numpy(), sn[k].numpy(), f"SN buffer {k} vs oracle", 1e-4)
-        _scale_close(probe(v.cpu(), k), f[f"{tag}/d/buf/{k}"], f"SN buffer {k} vs golden", 1e-4)
-    met = eng.g_step(batch, cuda(z2))
-    o_met, o_grads = O.g_step_sn(g_sd, d_sd, sn, g_opt, z2, size)
-    # (second chained step against a free-running oracle: a borderline activation sign moves single elements by ~1e-2)
-    check("g", met, o_met, o_grads, g_sd, g_opt, f"{tag}/g", 5e-2 if batch == 4 else 2e-2)
-    for k, v in eng.sn_views().items():                       # D.eval(): untouched
+    s_d = hip_signs_d(eng, size, batch, 2)
+    d_hip = {k: v.cpu().clone() for k, v in eng.views("d", "grads").items()}
+    sn_hip = {k: v.cpu().clone() for k, v in eng.sn_views().items()}
+    # ---- G step on the state the D step left ----
+    gmet = eng.g_step(batch, cuda(z2))
+    s_g = hip_signs_g(eng, size, batch) + hip_signs_d(eng, size, batch, 1)
+    g_hip = {k: v.cpu().clone() for k, v in eng.views("g", "grads").items()}
+
+    def run(signs_d, signs_g, rec_d=None, rec_g=None):
+        g_sd, d_sd, g_opt, d_opt, sn = _sn_states(size, latent)
+        dm, dg = O.d_step_sn(g_sd, d_sd, sn, d_opt, real, z, masks[:nb], masks[nb:], size, signs=signs_d, record=rec_d)
+        sn_after_d = {k: v.clone() for k, v in sn.items()}
+        gm, gg = O.g_step_sn(g_sd, d_sd, sn, g_opt, z2, size, signs=signs_g, record=rec_g)
+        return dm, dg, gm, gg, sn_after_d, g_sd, d_sd, g_opt, d_opt
+    rec_d, rec_g = [], []
+    dm, dg, gm, gg, sn_b, g_sd, d_sd, g_opt, d_opt = run(s_d, s_g, rec_d, rec_g)
+    count_sign_flips(s_d, rec_d, keep=masks)
+    count_sign_flips(s_g, rec_g)
+    for k, v in dm.items():
+        assert_close(met[k], v, 2e-4, 2e-6, f"SN d metric {k} vs oracle")
+        assert_close(met[k], f[f"{tag}/d/metric/{k}"], 2e-4, 2e-6, f"SN d metric {k} vs golden")
+    for k, v in gm.items():
+        assert_close(gmet[k], v, 2e-4, 2e-6, f"SN g metric {k} vs oracle")
+        assert_close(gmet[k], f[f"{tag}/g/metric/{k}"], 2e-4, 2e-6, f"SN g metric {k} vs golden")
+    sc_d, _ = _scales(dg, list(dg), np.array([float(dg[k].norm()) for k in dg]))
+    sc_g, _ = _scales(gg, list(gg), f[f"{tag}/g/grad_norm"])
+    # (round 2 allowed 5e-3 here and blamed the cancellation in G / sigma - (<G, W> / sigma^2) u v^T; with the sign decisions
+    # shared the arithmetic agrees to 1.4e-6 / 1.5e-5 -- it was the decisions all along)
+    row["hip_vs_oracle_with_hip_signs_d"] = max(float((d_hip[k] - dg[k]).abs().max()) / sc_d[k] for k in dg)
+    row["hip_vs_oracle_with_hip_signs_g"] = max(float((g_hip[k] - gg[k]).abs().max()) / sc_g[k] for k in gg)
+    assert row["hip_vs_oracle_with_hip_signs_d"] <= 1e-4 and row["hip_vs_oracle_with_hip_signs_g"] <= 1e-4, row
+    for k, v in sn_hip.items():                                # two power iterations later
+        _scale_close(v.numpy(), sn_b[k].numpy(), f"SN buffer {k} vs oracle", 1e-4)
+        _scale_close(probe(v, k), f[f"{tag}/d/buf/{k}"], f"SN buffer {k} vs golden", 1e-4)
+    for k, v in eng.sn_views().items():                        # D.eval(): untouched by the G step
         _scale_close(probe(v.cpu(), k), f[f"{tag}/g/dbuf/{k}"], f"SN buffer {k} after the G step", 1e-5)
+    i_g, i_d, i_gopt, i_dopt, _ = _sn_states(size, latent)
+    for which, og, oopt, sc, isd, iopt in (("d", dg, d_opt, sc_d, i_d, i_dopt), ("g", gg, g_opt, sc_g, i_g, i_gopt)):
+        mv = eng.views(which, "exp_avg")
+        for k in mv:
+            assert float((mv[k].cpu() - oopt.m[k]).abs().max()) <= 1e-4 * sc[k], (which, k, "exp_avg")
+        _weights_in_envelope(eng, which, og, sc, isd, iopt, 1e-4, oopt.step, f"SN {which}")
+    # ---- the reference run's own decisions -> the fixture, on this host; HIP decisions counted against them ----
+    _, cdg, _, cgg, *_ = run(census_signs(f, f"{tag}/d"), census_signs(f, f"{tag}/g"))
+    row["oracle_with_reference_signs_vs_reference_d"] = max(float(np.abs(probe(cdg[k], ren(k)) - f[f"{tag}/d/grad/{ren(k)}"]).max()) / sc_d[k] for k in cdg)
+    row["oracle_with_reference_signs_vs_reference_g"] = _golden_rel(f, f"{tag}/g", cgg, list(cgg), sc_g)
+    assert row["oracle_with_reference_signs_vs_reference_d"] <= 1e-4 and row["oracle_with_reference_signs_vs_reference_g"] <= 1e-4, row
+    fl_d = flips_vs_census(f, f"{tag}/d", s_d, keep=masks)
+    fl_g = flips_vs_census(f, f"{tag}/g", s_g)
+    row["flips_vs_reference_d"], row["flips_vs_reference_g"] = len(fl_d), len(fl_g)
+    hip_d = max(float(np.abs(probe(d_hip[k], ren(k)) - f[f"{tag}/d/grad/{ren(k)}"]).max()) / sc_d[k] for k in d_hip)
+    prd_d = max(float(np.abs(probe(dg[k], ren(k)) - f[f"{tag}/d/grad/{ren(k)}"]).max()) / sc_d[k] for k in dg)
+    hip_g, prd_g = _golden_rel(f, f"{tag}/g", g_hip, list(gg), sc_g), _golden_rel(f, f"{tag}/g", gg, list(gg), sc_g)
+    row.update(hip_vs_reference_d=hip_d, hip_vs_reference_g=hip_g, predicted_by_the_flips_d=prd_d, predicted_by_the_flips_g=prd_g)
+    assert (hip_d <= 1e-3) if not fl_d else (abs(hip_d - prd_d) <= 1e-3), row
+    assert (hip_g <= 1e-3) if not (fl_d or fl_g) else (abs(hip_g - prd_g) <= 1e-3), row
+    MARGINS[f"spectral_norm/{tag}"] = row
+    _dump_margins()
     eng.close()
 
 
