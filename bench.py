@@ -197,6 +197,7 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="batch PER GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented pass")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the generation-throughput pass (the `secondary` object)")
     ap.add_argument("--serialize", action="store_true",
                     help="run every pass with side-lane overlap OFF (one kernel at a time): the mode the roofline "
                          "pass always uses, and the one to profile with rocprofv3 so per-kernel durations agree")
@@ -377,7 +378,7 @@ def main(argv=None):
                                                     "algorithmic_gbps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in recs}},
         }
     secondary = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not args.no_secondary:
         # generation throughput (Generator.forward in eval mode, vanilla_gan_model.py:338-371) beside the headline,
         # same engine / weights / batch; MFMA kernels stamped one at a time as above (profiles/secondary.py has the wider table)
         gflop = {64: 87.06e6, 128: 414.19e6}[size] + 2 * (4096 if size == 64 else 8192) * (latent - (100 if size == 64 else 128))

@@ -4,7 +4,6 @@
 // segments) and per-channel reductions are two-stage (per-chunk partials, then a finalize
 // kernel that adds the partials in chunk order), so results are bitwise reproducible.
 #include "ops.h"
-#include "gconv.h"   // exp_knob
 #include "rng.h"
 
 namespace siggan {

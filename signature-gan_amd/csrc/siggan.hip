@@ -173,6 +173,10 @@ struct siggan_ctx {
     // data-parallel communicator (siggan_comm_init): world 1 = none
     ncclComm_t comm; int comm_rank, comm_world; int comm_err;
     int staged_B;        // batch of a real batch staged for the NEXT D step by siggan_stage_real (0: none)
+    bool gfwd_joined;    // the pipelined Generator forward's lane was already joined into the caller's stream (end of the D grads phase)
+    bool dreal_joined;   // the lane of that early forward was already joined into the caller's stream (end of the G step)
+    bool dreal_noise2;   // its launch also drew the dropout tables of the D(fake) pass
+    float* slab_b;       // second weight-gradient slab region (a weight gradient on the main lane beside lane a's)
     const float* staged_src;   // where that batch lies: the caller's own tensor (borrowed until the D step that consumes it)
     int dreal_B;         // batch whose D(real) forward siggan_g_grads already enqueued on lane c (0: none)
     int zg_stash;        // batch of an explicit G-step z handed to siggan_step_begin when the forward was not pipelined
@@ -318,6 +322,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->wcp, (int64_t)c->dC[c->Ld] * 16);
         carve(&c->slab, c->slab_floats);
         carve(&c->slab_k, c->slab_k_floats);
+        if (c->dt != DT_F32) carve(&c->slab_b, c->slab_floats); else if (pass == 1) c->slab_b = c->slab;
         carve(&c->slab_k2, c->slab_k_floats);
         if (c->dt != DT_F32) carve(&c->slab_k3, c->slab_k_floats); else if (pass == 1) c->slab_k3 = c->slab_k2;
         carve(&c->partial, (int64_t)2 << 20);
@@ -363,7 +368,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->s_c, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_gfwd, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_dreal, hipEventDisableTiming));
-    c->staged_B = c->dreal_B = 0; c->staged_src = nullptr;
+    c->staged_B = c->dreal_B = 0; c->staged_src = nullptr; c->dreal_joined = c->dreal_noise2 = c->gfwd_joined = false;
     c->dreal_orphan = false; c->lane_err = hipSuccess;
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1; c->comm_err = 0;
     c->g_fwd_pending = 0;
@@ -704,14 +709,21 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
         launch_cls_wgrad(c->dt, c->dlogit + r0, act(Ld), G_(di_cls_w(c)), G_(di_cls_b(c)), Bd, c->dC[Ld], sb);
     for (int l = Ld; l >= 2; --l) {
         const int Ho = c->S >> l, Hi = 2 * Ho, Co = c->dC[l], Ci = c->dC[l - 1];
-        if (want_wgrad) {
-            L.fork(L.a);                                   // d_dv[l] is complete on m here
+        // 16-bit contexts (launch-latency-bound): the LAST block's weight gradient runs behind the input-gradient chain on the
+        // main lane, own slab, so that lane a ends before the main lane does (measured with the three 16-bit lane rules
+        // together: bf16 0.718 -> 0.707 ms; at fp32 each is within noise and the plain structure stays)
+        const bool w_main = want_wgrad && l == 2 && c->dt != DT_F32 && garena == nullptr;
+        auto wgrad_l = [&](hipStream_t st, float* slab) {
             WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
-            w.S = dvp(l); w.L = act(l - 1); w.slab = c->slab; w.dw = G_(di_w(l)); w.B = Bd; w.Cs = Co; w.Cl = Ci;
+            w.S = dvp(l); w.L = act(l - 1); w.slab = slab; w.dw = G_(di_w(l)); w.B = Bd; w.Cs = Co; w.Cl = Ci;
             w.lgHs = ilog2i(Ho); w.lgWs = w.lgHs; w.lgCl = ilog2i(Ci); w.K = Bd * Ho * Ho;
             w.db = G_(di_b(l));                              // bias gradient = column sums of d(pre-activation): rides in the same kernel
             const int max_splits = (int)(c->slab_floats / ((int64_t)Co * (16 * Ci + 1)));
-            launch_wgrad(w, max_splits, L.a);
+            launch_wgrad(w, max_splits, st);
+        };
+        if (want_wgrad && !w_main) {
+            L.fork(L.a);                                   // d_dv[l] is complete on m here
+            wgrad_l(L.a, c->slab);
         }
         // input gradient ("up" form): contract Cout, produce Cin at (Hi x Hi); fused leaky'/dropout of block l-1
         GConvArgs a = gconv_args(c);
@@ -720,8 +732,16 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
         a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 1; a.M = Bd * Ho * Ho;
         a.epi = EPI_LRELU_BWD; a.aref = act(l - 1); a.noise = nz(l - 1); a.slope = slope;
         launch_gconv(a, L.m);
+        if (w_main) {
+            L.fork(L.b);                                   // (the first-block reductions start here, beside the weight gradient)
+            launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
+            wgrad_l(L.m, c->slab_b);
+        }
     }
-    if (want_wgrad) {
+    if (want_wgrad && c->dt != DT_F32 && garena == nullptr) {
+        L.join(L.a);
+        L.join(L.b);
+    } else if (want_wgrad) {
         L.fork(L.b);
         launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
         L.join(L.a);
@@ -843,14 +863,25 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     if (c->sn) return phase_d_grads_sn(c, L, k);
     const int B = k.B;
     const bool drop = c->cfg.dropout > 0.f;
+    // A staged step whose D(real) forward already ran has nothing for lane a: the real batch is read where it lies (no copy:
+    // the borrowed tensor is valid until this call returns), the dropout tables of BOTH passes were drawn when that forward
+    // was launched -- no fork, no join, two launches fewer in the step's first 100 us (+0.4 %)
+    const bool nolane = k.pre_real == 2 && !k.d_dirty && (!drop || c->dreal_noise2);
+    const float* xreal = c->real_stage;
+    if (nolane) {
+        repack(c, L.m, L.m, k.g_dirty != 0, false);
+        xreal = c->staged_src;
+    } else {
     L.fork(L.a);                                                     // lane a: D's packs, dropout tables, D(real)
     repack(c, L.m, L.a, k.g_dirty != 0, k.d_dirty != 0);
     if (k.pre_real)      // staged batch -> this step's real batch (the D backward reads it again)
         L.note(hipMemcpyAsync(c->real_stage, c->staged_src, (size_t)B * c->S * c->S * sizeof(float), hipMemcpyDeviceToDevice, L.a));
-    if (drop) make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, k.pre_real == 2 ? 1 : 0, 2, L.a);
+    if (drop && !(k.pre_real == 2 && c->dreal_noise2))
+        make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, k.pre_real == 2 ? 1 : 0, 2, L.a);
     // D(real) beside the Generator (train...py:309) -- unless the previous siggan_g_grads already ran it
     // (siggan_stage_real) beside its Generator backward; then bce only has to wait for that lane
     if (k.pre_real != 2) d_forward_rows(c, c->real_stage, 0, B, drop, L.a, c->slab_k2);
+    }
     const float* fake = c->img;
     const bool spec_fwd = k.spec_g && k.variant != SIGGAN_STEP_ABLATION;
     // siggan_step_begin: the G step's training forward depends on nothing the D step changes.  16-bit contexts (every kernel
@@ -876,7 +907,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k3, 2, c->z_g);
         L.record(c->ev_gfwd, c->s_c);
     }
-    L.join(L.a);
+    if (!nolane) L.join(L.a);
     // siggan_step_begin: the G step's training forward depends on nothing the D step changes, so it
     // runs on its own lane beside D(fake) and the D step's backward (after the eval forward above: it
     // moves the BatchNorm running statistics and reuses the activation buffers; its own image / z /
@@ -884,13 +915,18 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     hipEvent_t e_spec = nullptr;
     if (spec_fwd && !spec_early) { e_spec = L.next(); L.record(e_spec, L.m); }
     d_forward_rows(c, fake, B, B, drop, L.m, c->slab_k);             // D(fake) into rows [B, 2B)
-    if (k.pre_real == 2) L.wait(L.m, c->ev_dreal);
+    if (k.pre_real == 2 && !c->dreal_joined) L.wait(L.m, c->ev_dreal);
+    c->dreal_joined = c->dreal_noise2 = false;
     if (spec_fwd && !spec_early) {
         L.wait(c->s_c, e_spec);
         g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2, 2, c->z_g);
         L.record(c->ev_gfwd, c->s_c);
     }
-    d_backward_pass(c, L, c->real_stage, B, fake, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0});
+    d_backward_pass(c, L, xreal, B, fake, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0});
+    // 16-bit contexts: the pipelined forward ended long ago -- wait for it here, next to the two joins of this phase, instead of
+    // between the optimiser and the G step's first kernel
+    c->gfwd_joined = false;
+    if (spec_fwd && c->dt != DT_F32) { L.wait(L.m, c->ev_gfwd); c->gfwd_joined = true; }
 }
 
 static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
@@ -899,7 +935,8 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const bool d_pack = !c->sn && k.d_dirty != 0;                    // (spectral norm: the packs follow sigma, below)
     if (k.spec_g) {                                                  // forward already enqueued by siggan_step_begin
         repack(c, L.m, L.m, false, d_pack);
-        L.wait(L.m, c->ev_gfwd);
+        if (!c->gfwd_joined) L.wait(L.m, c->ev_gfwd);
+        c->gfwd_joined = false;
         zg = c->z_g; img = c->img_g;
     } else {
         L.fork(L.a);
@@ -932,7 +969,8 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     if (real_early) {
         const bool drop = c->cfg.dropout > 0.f;
         L.fork(c->s_c);                                               // D's packs are complete on m here
-        if (drop) make_noise(c, nullptr, B, 0, 1, c->s_c, 1);
+        if (drop) make_noise(c, nullptr, B, 0, 2, c->s_c, 1);       // the D(fake) pass' tables too (this G step's pass has no dropout)
+        c->dreal_noise2 = drop;
         d_forward_rows(c, c->staged_src, 0, B, drop, c->s_c, c->slab_k2);
         L.record(c->ev_dreal, c->s_c);
     }
@@ -950,6 +988,9 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         L.record(c->ev_dreal, c->s_c);
     }
     g_backward_pass(c, L, zg, B);
+    // 16-bit contexts: join the early D(real) lane HERE, next to the join of the weight-gradient lane, so that the next D step
+    // does not stop for it behind D(fake)
+    if (real_early && c->dt != DT_F32) { L.wait(L.m, c->ev_dreal); c->dreal_joined = true; }
 }
 
 static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
