@@ -227,7 +227,11 @@ int siggan_d_grads(siggan_ctx *ctx, const float *real_dev, int32_t batch, const 
  * RNG when NULL) on its own lane beside the D step's backward -- that forward depends on nothing the D
  * step changes (train_vanilla_gan_signatures.py:349-357).  Must be followed by siggan_d_apply and then
  * siggan_g_grads(batch, z_dev = NULL), which picks the forward up.  Results are bit-identical to the
- * un-pipelined calls; without SIGGAN_MODE_OVERLAP it degrades to siggan_d_grads. */
+ * un-pipelined calls; without SIGGAN_MODE_OVERLAP it degrades to siggan_d_grads.
+ * With a communicator this call (like siggan_d_step, and unlike siggan_d_grads, which never starts a collective) already
+ * issues the all-reduce of the last Discriminator block's weight gradient -- three quarters of the D bucket, complete first
+ * -- on a lane of its own under the rest of the backward pass; siggan_d_apply reduces the remainder and waits for it.  EVERY
+ * rank must therefore follow it with siggan_d_apply. */
 int siggan_step_begin(siggan_ctx *ctx, const float *real_dev, int32_t batch, const float *z_dev,
                       const float *masks_dev, const float *zg_dev, const siggan_hyper *hp,
                       float *metrics_dev, void *stream);

@@ -330,8 +330,11 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int N = 16 << a.lgCl;
     const int tiles_n = N / BN;
-    const int i0 = (blockIdx.x / tiles_n) * BM, j0 = (blockIdx.x % tiles_n) * BN;
-    const int kbeg = blockIdx.z * a.kchunk;
+    // (XCD-aware order, as in k_wgrad: the tiles of one K split share an XCD's L2)
+    const int lid = xcd_remap16(blockIdx.z * gridDim.x + blockIdx.x, gridDim.x * gridDim.z);
+    const int bx = lid % gridDim.x, bz = lid / gridDim.x;
+    const int i0 = (bx / tiles_n) * BM, j0 = (bx % tiles_n) * BN;
+    const int kbeg = bz * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
     const int nk = (kend - kbeg + BKP - 1) / BKP;
     const int Hs = 1 << a.lgHs, Ws = 1 << a.lgWs, Hl = 2 * Hs, Wl = 2 * Ws, Cl = 1 << a.lgCl;
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
 #pragma unroll
             for (int q = 1; q < NQ; ++q) t += fsm[q * BM + tid];
             if (gridDim.z == 1) a.db[i0 + tid] = t;
-            else a.slab[(size_t)gridDim.z * a.Cs * N + (size_t)blockIdx.z * a.Cs + i0 + tid] = t;
+            else a.slab[(size_t)gridDim.z * a.Cs * N + (size_t)bz * a.Cs + i0 + tid] = t;
         }
     }
     const int li2 = lane & 31, lh2 = lane >> 5;
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void k_wgrad16(const WgradArgs a) {
             }
         return;
     }
-    float* const out = a.slab + (size_t)blockIdx.z * a.Cs * N;
+    float* const out = a.slab + (size_t)bz * a.Cs * N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll

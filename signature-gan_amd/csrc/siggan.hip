@@ -110,14 +110,14 @@ static Rccl* rccl() {
     } while (0)
 
 struct PhaseKey {
-    int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg, pre_real, variant;
+    int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg, pre_real, variant, coll;   // coll: an apply call follows (collectives may start early)
     float* mt;   // where the phase writes its metrics (caller's buffer, or the workspace one)
     double lr, beta1, beta2, eps;
     double fused_t;   // > 0: the step count (after the increment) of a one-launch optimiser update; 0: k_adam_prepare path
     float ls, clip, gs;
     bool operator==(const PhaseKey& o) const {
         return phase == o.phase && B == o.B && has_z == o.has_z && has_masks == o.has_masks && g_dirty == o.g_dirty &&
-               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && pre_real == o.pre_real && variant == o.variant && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
+               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && pre_real == o.pre_real && variant == o.variant && coll == o.coll && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
                clip == o.clip && gs == o.gs && fused_t == o.fused_t;
     }
 };
@@ -166,8 +166,9 @@ struct siggan_ctx {
     // lanes / graphs
     static constexpr int NEV = 96;
     int mode;
-    hipStream_t s_m, s_a, s_b, s_c;
-    hipEvent_t ev_gfwd, ev_dreal;
+    hipStream_t s_m, s_a, s_b, s_c, s_n;      // s_n: the lane of an all-reduce issued while the backward pass is still running
+    hipEvent_t ev_gfwd, ev_dreal, ev_ar;
+    bool early_ar;       // the last D block's weight gradient is already being all-reduced on s_n (ev_ar marks its end)
     bool dreal_orphan;   // a D(real) forward enqueued on lane c was abandoned: the next enqueue waits for ev_dreal first
     hipError_t lane_err; // first failed event record / wait of a fork or join (checked after every phase)
     // data-parallel communicator (siggan_comm_init): world 1 = none
@@ -366,8 +367,11 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->s_a, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->s_b, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->s_c, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->s_n, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_gfwd, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_dreal, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_ar, hipEventDisableTiming));
+    c->early_ar = false;
     c->staged_B = c->dreal_B = 0; c->staged_src = nullptr; c->dreal_joined = c->dreal_noise2 = c->gfwd_joined = false;
     c->dreal_orphan = false; c->lane_err = hipSuccess;
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1; c->comm_err = 0;
@@ -393,6 +397,8 @@ extern "C" int siggan_destroy(siggan_ctx* c) {
     if (c->s_a) (void)hipStreamDestroy(c->s_a);
     if (c->s_b) (void)hipStreamDestroy(c->s_b);
     if (c->s_c) (void)hipStreamDestroy(c->s_c);
+    if (c->s_n) (void)hipStreamDestroy(c->s_n);
+    if (c->ev_ar) (void)hipEventDestroy(c->ev_ar);
     if (c->ev_gfwd) (void)hipEventDestroy(c->ev_gfwd);
     if (c->ev_dreal) (void)hipEventDestroy(c->ev_dreal);
     if (c->ws) (void)hipFree(c->ws);
@@ -685,7 +691,8 @@ struct BceSpec { int n0; float y0, y1; float* mt; int is_g; };   // rows < n0: t
 // r0 / garena (spectral norm: one pass at a time): the Bd rows start at workspace row r0 and the gradients go to garena
 // (an arena-shaped temporary) instead of the bound arena.
 static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, const float* x1, int Bd, bool dropout,
-                            bool want_wgrad, bool want_dimage, const BceSpec& bce, int r0 = 0, float* garena = nullptr) {
+                            bool want_wgrad, bool want_dimage, const BceSpec& bce, int r0 = 0, float* garena = nullptr,
+                            bool early_allreduce = false) {
     const float slope = c->cfg.leaky_slope;
     const int Ld = c->Ld;
     float* const ga = garena ? garena : c->st.d_grads;
@@ -724,6 +731,19 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
         if (want_wgrad && !w_main) {
             L.fork(L.a);                                   // d_dv[l] is complete on m here
             wgrad_l(L.a, c->slab);
+            if (early_allreduce && l == Ld && c->comm && !c->comm_err && garena == nullptr) {
+                // data parallel: the tail of the Discriminator's bucket -- the LAST block's weight (76 % of the bucket) and bias
+                // gradient (this kernel, lane a) and the classifier's (k_cls_wgrad, lane b) -- is complete first: its
+                // all-reduce starts now, on a lane of its own, under the rest of the backward pass; *_apply reduces the head of
+                // the arena and waits for this one (same sums: an all-reduce is elementwise)
+                hipEvent_t ea = L.next(), eb = L.next();
+                L.record(ea, L.a); L.record(eb, sb);
+                L.wait(c->s_n, ea); L.wait(c->s_n, eb);
+                const int64_t o = c->d_off[di_w(l)];
+                const int rc = rccl()->AllReduce(ga + o, ga + o, (size_t)(c->d_total - o), NCCL_FLOAT32, NCCL_SUM, c->comm, c->s_n);
+                if (rc != NCCL_SUCCESS) c->comm_err = rc;
+                else { L.record(c->ev_ar, c->s_n); c->early_ar = true; }
+            }
         }
         // input gradient ("up" form): contract Cout, produce Cin at (Hi x Hi); fused leaky'/dropout of block l-1
         GConvArgs a = gconv_args(c);
@@ -922,7 +942,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2, 2, c->z_g);
         L.record(c->ev_gfwd, c->s_c);
     }
-    d_backward_pass(c, L, xreal, B, fake, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0});
+    d_backward_pass(c, L, xreal, B, fake, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0}, 0, nullptr, k.coll != 0);
     // 16-bit contexts: the pipelined forward ended long ago -- wait for it here, next to the two joins of this phase, instead of
     // between the optimiser and the G step's first kernel
     c->gfwd_joined = false;
@@ -1014,8 +1034,17 @@ static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         // the update is skipped and lane_check hands the error to the caller (sticky: every later call returns it until
         // siggan_comm_destroy)
         if (c->comm_err) return;
+        if (which == 1 && c->early_ar) {
+            // the tail of the arena (last block + classifier) went ahead (d_backward_pass): the head now
+            const int64_t o = c->d_off[di_w(c->Ld)];
+            const int e = rccl()->AllReduce(g, g, (size_t)o, NCCL_FLOAT32, NCCL_SUM, c->comm, L.m);
+            c->early_ar = false;
+            if (e != NCCL_SUCCESS) { c->comm_err = e; return; }
+            L.wait(L.m, c->ev_ar);
+        } else {
         const int e = rccl()->AllReduce(g, g, (size_t)n, NCCL_FLOAT32, NCCL_SUM, c->comm, L.m);
         if (e != NCCL_SUCCESS) { c->comm_err = e; return; }
+        }
         gs *= 1.0f / (float)c->comm_world;
     }
     const bool guard = c->dt == DT_F16;                              // static gradient scale: skip the update on an overflow
@@ -1156,7 +1185,8 @@ extern "C" int siggan_d_forward(siggan_ctx* c, const float* x_dev, int32_t batch
 }
 
 static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
-                          const siggan_hyper* hp, float* metrics_dev, void* stream, bool spec_g, const float* zg_dev) {
+                          const siggan_hyper* hp, float* metrics_dev, void* stream, bool spec_g, const float* zg_dev,
+                          bool apply_follows = false) {
     ENTER(c);
     int rc = check_call(c, batch);
     if (rc) return rc;
@@ -1197,6 +1227,7 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     PhaseKey k = make_key(c, 0, B, z_dev != nullptr, masks_dev != nullptr, hp, metrics_dev);
     c->metrics_last = k.mt;
     k.spec_g = spec_g; k.has_zg = spec_g && zg_dev != nullptr; k.pre_real = pre_real; k.variant = c->variant;
+    k.coll = apply_follows && c->comm != nullptr;
     if ((rc = run_phase(c, k, s))) return rc;
     c->g_dirty = c->d_dirty = false;
     if (spec_g) { c->g_fwd_pending = B; c->g_dirty = true; }   // running statistics moved
@@ -1225,7 +1256,7 @@ extern "C" int siggan_d_grads(siggan_ctx* c, const float* real_dev, int32_t batc
 
 extern "C" int siggan_step_begin(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
                                  const float* zg_dev, const siggan_hyper* hp, float* metrics_dev, void* stream) {
-    return d_grads_common(c, real_dev, batch, z_dev, masks_dev, hp, metrics_dev, stream, true, zg_dev);
+    return d_grads_common(c, real_dev, batch, z_dev, masks_dev, hp, metrics_dev, stream, true, zg_dev, true);
 }
 
 static int apply_common(siggan_ctx* c, int which, const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
@@ -1274,7 +1305,7 @@ extern "C" int siggan_d_apply(siggan_ctx* c, const siggan_hyper* hp, float* metr
 
 extern "C" int siggan_d_step(siggan_ctx* c, const float* real_dev, int32_t batch, const float* z_dev, const float* masks_dev,
                              const siggan_hyper* hp, float* metrics_dev, float* metrics_host, void* stream) {
-    int rc = siggan_d_grads(c, real_dev, batch, z_dev, masks_dev, hp, metrics_dev, stream);
+    int rc = d_grads_common(c, real_dev, batch, z_dev, masks_dev, hp, metrics_dev, stream, false, nullptr, true);
     if (rc) return rc;
     return siggan_d_apply(c, hp, metrics_dev, metrics_host, stream);
 }
