@@ -32,7 +32,7 @@ void launch_mask_to_noise(const float* mask, float* out, int64_t n, float keep, 
 void launch_tick(DevState* st, hipStream_t s);
 
 // ---- fused "prepare" pass: every weight re-pack / BN-eval fold of one network in ONE launch -----
-enum PrepType : int { PREP_PACK_DOWN = 0, PREP_PACK_UP, PREP_FC_T, PREP_CLS, PREP_BN_EVAL, PREP_SCALE };
+enum PrepType : int { PREP_PACK_DOWN = 0, PREP_PACK_UP, PREP_FC_T, PREP_CLS, PREP_BN_EVAL, PREP_SCALE, PREP_TAPS };
 struct PrepJob {
     int type, O, I, perm;        // PACK_*: (O,I) channel counts; FC_T: O=K, I=C0; CLS: O=C; BN_EVAL: O=C, perm=perm_c0
     int dt;                      // PACK_DOWN / PACK_UP: element type of dst (DT_F32 / DT_BF16 / DT_F16); fp32 for the rest
@@ -91,16 +91,16 @@ void launch_bn_bwd(int dt, void* da, const void* y, int64_t R, int C, float* bn,
 // final 3x3 conv (C->1) + tanh, and its backward pieces.  act: [B][S][S][C] NHWC, img [B][S][S].
 // bn != nullptr (training): `act` is the last block's PRE-BatchNorm tensor y and bn its [scale | shift] table -- the
 // activation relu(fma(y, scale, shift)) is formed on load and never stored
-void launch_final_fwd(int dt, const void* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s,
+void launch_final_fwd(int dt, const void* act, const float* Wt, const float* b, float* img, int B, int S, int C, hipStream_t s,
                       const float* bn = nullptr);
 // backward of the last Generator block from dpre.  (1) launch_final_bwd_reduce: ONE read of y gives the BatchNorm-backward sums
 // (d(act) of the final conv recomputed from dpre, never stored; relu mask re-derived from y) into `partial` AND the partial
 // rows of the final conv's weight / bias gradient (activation re-derived from y) into `partial_w`;  (2) launch_final_wgrad_fin:
 // dW / db from partial_w (any lane);  (3) launch_final_bn_bwd_apply: dgamma / dbeta + dy from `partial`
-void launch_final_bwd_reduce(int dt, const float* dpre, const float* W, const void* y, int B, int S, int C, const float* bn,
+void launch_final_bwd_reduce(int dt, const float* dpre, const float* Wt, const void* y, int B, int S, int C, const float* bn,
                              float* partial, float* partial_w, hipStream_t s);
 void launch_final_wgrad_fin(const float* partial_w, float* dW, float* db, int B, int S, int C, hipStream_t s);
-void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* W, const void* y, void* dy, int B, int S, int C, float* bn,
+void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* Wt, const void* y, void* dy, int B, int S, int C, float* bn,
                                const float* partial, float* dgamma, float* dbeta, hipStream_t s);
 
 // ---- Discriminator pieces -----------------------------------------------------------------
@@ -110,7 +110,7 @@ void launch_conv1_fwd(int dt, const float* x0, int n0, const float* x1, const fl
 void launch_conv1_wgrad(int dt, const void* dv, const float* x0, int n0, const float* x1, float* dW, float* db,
                         float* partial, int B, int S, int C, hipStream_t s);
 // d(image) = conv1 input-gradient, times tanh' = 1 - img^2  ->  dpre
-void launch_conv1_dgrad_tanh(int dt, const void* dv, const float* W, const float* img, float* dpre, int B, int S,
+void launch_conv1_dgrad_tanh(int dt, const void* dv, const float* Wt, const float* img, float* dpre, int B, int S,
                              int C, hipStream_t s);
 void launch_cls_fwd(int dt, const void* act, const float* wcp, const float* bc, float* logits, int B, int F, hipStream_t s);
 void launch_cls_features(int dt, const void* act, float* feat, int B, int C, hipStream_t s);

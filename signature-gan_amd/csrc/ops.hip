@@ -66,6 +66,7 @@ __device__ __forceinline__ int perm16(int c, int perm_c0) { return perm_c0 > 0 ?
 //   PACK_DOWN  unit = output channel o : w[o][i][tap]     -> dst[o][tap*I + i]          (I*16 floats)
 //   PACK_UP    unit = output channel o : w[i][o][kh][kw]  -> dst[cls][o][t*I + i]       (I*16 floats)
 //   FC_T       unit = 64 features x <=128 latent dims    : W[f][k] -> Wt[k][f']
+//   TAPS       unit = 256 elements of a one-channel conv's weight (final conv, first D block): w[c][tap] -> dst[tap][c]
 //   BN_EVAL    unit = 256 channels
 static long long prep_units(const PrepJob& j) {
     switch (j.type) {
@@ -73,6 +74,7 @@ static long long prep_units(const PrepJob& j) {
         case PREP_PACK_UP: return j.O;
         case PREP_FC_T: return (long long)(j.I * 16 / 64) * ((j.O + 127) / 128);
         case PREP_SCALE: return (j.O + 1023) / 1024;
+        case PREP_TAPS: return (j.O * j.I + 255) / 256;
         default: return (j.O + 255) / 256;
     }
 }
@@ -140,6 +142,9 @@ __global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
         }
         __syncthreads();
         for (int e = tid; e < 64 * kn; e += 256) { const int k = e >> 6, r = e & 63; q.dst[(size_t)(k0 + k) * F + f0 + r] = tile[r * 129 + k]; }
+    } else if (q.type == PREP_TAPS) {            // one-channel convs: w[c][tap] -> dst[tap][c] (I taps, O channels), 256 elements per unit
+        const int e = u * 256 + tid;
+        if (e < q.O * q.I) q.dst[(e % q.I) * q.O + e / q.I] = q.mul ? q.src[e] * q.mul[0] : q.src[e];
     } else if (q.type == PREP_SCALE) {           // dst = src * mul (fp32), 1024 elements per unit
         const float m = q.mul ? q.mul[0] : 1.0f;
         for (int e = u * 1024 + tid; e < min(q.O, (u + 1) * 1024); e += 256) q.dst[e] = q.src[e] * m;
@@ -535,18 +540,15 @@ __device__ __forceinline__ StripId strip_of(int sid, int S, int xi) {
 // (k_bn_relu's own expression) is formed on load and never stored -- in training mode nothing else reads it in the
 // forward pass, and the backward pass re-derives it from y as well (k_final_bwd_reduce).
 template <class T, bool BN>
-__global__ __launch_bounds__(256) void k_final_fwd(const T* __restrict__ act, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void k_final_fwd(const T* __restrict__ act, const float* __restrict__ Wt,
                                                    const float* __restrict__ b, float* __restrict__ img, int S,
                                                    const float* __restrict__ bn) {
     constexpr int RY = 4, C = 32;
     const int c4 = threadIdx.x & 7;
     const StripId t = strip_of<RY>(blockIdx.x, S, threadIdx.x >> 3);
-    __shared__ __attribute__((aligned(16))) float sw9[9 * 36];     // W[c][tap] -> [tap][c] (row stride 36), one coalesced pass
-    for (int i = threadIdx.x; i < 9 * 32; i += 256) sw9[(i % 9) * 36 + i / 9] = W[i];
-    __syncthreads();
-    f4v w[9];
+    f4v w[9];                         // Wt = the weight as [tap][c] (k_prepare's PREP_TAPS copy): no LDS transpose, no barrier in front of the strip
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f4v*>(sw9 + k * 36 + c4 * 4);
+    for (int k = 0; k < 9; ++k) w[k] = ldg4(Wt + k * 32 + c4 * 4);
     const float bias = b[0];
     f4v sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
     if (BN) { sc = ldg4(bn + c4 * 4); sf = ldg4(bn + C + c4 * 4); }
@@ -578,13 +580,13 @@ __global__ __launch_bounds__(256) void k_final_fwd(const T* __restrict__ act, co
         if (c4 == 0) img[((size_t)t.n * S + t.y0 + r) * S + t.x] = tanhf(acc + bias);
     }
 }
-void launch_final_fwd(int dt, const void* act, const float* W, const float* b, float* img, int B, int S, int C, hipStream_t s,
+void launch_final_fwd(int dt, const void* act, const float* Wt, const float* b, float* img, int B, int S, int C, hipStream_t s,
                       const float* bn) {
     (void)C;                                            // host checks C == 32, S % 32 == 0
     const dim3 grid(B * (S / 4) * (S / 32));
     SIGGAN_DT_SWITCH(dt, T, {
-        if (bn) hipLaunchKernelGGL((k_final_fwd<T, true>), grid, dim3(256), 0, s, (const T*)act, W, b, img, S, bn);
-        else hipLaunchKernelGGL((k_final_fwd<T, false>), grid, dim3(256), 0, s, (const T*)act, W, b, img, S, bn);
+        if (bn) hipLaunchKernelGGL((k_final_fwd<T, true>), grid, dim3(256), 0, s, (const T*)act, Wt, b, img, S, bn);
+        else hipLaunchKernelGGL((k_final_fwd<T, false>), grid, dim3(256), 0, s, (const T*)act, Wt, b, img, S, bn);
     });
 }
 
@@ -630,7 +632,7 @@ __device__ __forceinline__ f4v final_dact(const float (&d)[RY + 2][3], const f4v
 // A block walks 8-row strips (grid-stride), folds the 32 pixel lanes (shuffles inside a wave, LDS across the 4 waves, fixed
 // order) and writes one partial row per output family; k_bn_bwd_fin / k_rows_sum add the rows.
 template <class T, int RY>
-__global__ __launch_bounds__(256) void k_final_bwd_reduce(const float* __restrict__ dpre, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void k_final_bwd_reduce(const float* __restrict__ dpre, const float* __restrict__ Wt,
                                                           const T* __restrict__ y, const float* __restrict__ bn,
                                                           float* __restrict__ p0, float* __restrict__ p1,
                                                           float* __restrict__ pw, int S, int nstrips) {
@@ -638,12 +640,9 @@ __global__ __launch_bounds__(256) void k_final_bwd_reduce(const float* __restric
     __shared__ f4v sh[2][4][8];
     __shared__ float shw[4][8][37];
     const int c4 = threadIdx.x & 7, wave = threadIdx.x >> 6;
-    __shared__ __attribute__((aligned(16))) float sw9[9 * 36];     // W[c][tap] -> [tap][c] (row stride 36), one coalesced pass
-    for (int i = threadIdx.x; i < 9 * 32; i += 256) sw9[(i % 9) * 36 + i / 9] = W[i];
-    __syncthreads();
-    f4v w[9];
+    f4v w[9];                         // Wt = the weight as [tap][c] (k_prepare's PREP_TAPS copy): no LDS transpose, no barrier in front of the strip
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f4v*>(sw9 + k * 36 + c4 * 4);
+    for (int k = 0; k < 9; ++k) w[k] = ldg4(Wt + k * 32 + c4 * 4);
     const f4v sc = ldg4(bn + c4 * 4), sf = ldg4(bn + C + c4 * 4), mu = ldg4(bn + 2 * C + c4 * 4), rs = ldg4(bn + 3 * C + c4 * 4);
     f4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     f4v acc[9];
@@ -729,18 +728,15 @@ __global__ __launch_bounds__(256) void k_final_bwd_reduce(const float* __restric
 }
 // stage 2 (after k_bn_bwd_fin): dy = scale * (dy_relu - c1 - xhat * c2), written to dy[B][S][S][C]
 template <class T>
-__global__ __launch_bounds__(256) void k_final_bnbwd_apply(const float* __restrict__ dpre, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void k_final_bnbwd_apply(const float* __restrict__ dpre, const float* __restrict__ Wt,
                                                            const T* __restrict__ y, const float* __restrict__ bn,
                                                            T* __restrict__ dy, int S) {
     constexpr int RY = 4, C = 32;
     const int c4 = threadIdx.x & 7;
     const StripId t = strip_of<RY>(blockIdx.x, S, threadIdx.x >> 3);
-    __shared__ __attribute__((aligned(16))) float sw9[9 * 36];     // W[c][tap] -> [tap][c] (row stride 36), one coalesced pass
-    for (int i = threadIdx.x; i < 9 * 32; i += 256) sw9[(i % 9) * 36 + i / 9] = W[i];
-    __syncthreads();
-    f4v w[9];
+    f4v w[9];                         // Wt = the weight as [tap][c] (k_prepare's PREP_TAPS copy): no LDS transpose, no barrier in front of the strip
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f4v*>(sw9 + k * 36 + c4 * 4);
+    for (int k = 0; k < 9; ++k) w[k] = ldg4(Wt + k * 32 + c4 * 4);
     const f4v sc = ldg4(bn + c4 * 4), sf = ldg4(bn + C + c4 * 4), mu = ldg4(bn + 2 * C + c4 * 4), rs = ldg4(bn + 3 * C + c4 * 4);
     const f4v c1 = ldg4(bn + 4 * C + c4 * 4), c2 = ldg4(bn + 5 * C + c4 * 4);
     float d[RY + 2][3];
@@ -778,22 +774,22 @@ constexpr int FINAL_RY = 4;
 static int final_reduce_rows(int B, int S) {
     const int n = B * (S / FINAL_RY) * (S / 32); return n < 512 ? n : 512;
 }
-void launch_final_bwd_reduce(int dt, const float* dpre, const float* W, const void* y, int B, int S, int C, const float* bn,
+void launch_final_bwd_reduce(int dt, const float* dpre, const float* Wt, const void* y, int B, int S, int C, const float* bn,
                              float* partial, float* partial_w, hipStream_t s) {
     const int nstrips = B * (S / FINAL_RY) * (S / 32), nch = final_reduce_rows(B, S);
     float* p0 = partial; float* p1 = partial + (size_t)nch * C;
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL((k_final_bwd_reduce<T, FINAL_RY>), dim3(nch), dim3(256), 0, s, dpre, W, (const T*)y, bn, p0, p1,
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL((k_final_bwd_reduce<T, FINAL_RY>), dim3(nch), dim3(256), 0, s, dpre, Wt, (const T*)y, bn, p0, p1,
                                                 partial_w, S, nstrips));
 }
 void launch_final_wgrad_fin(const float* partial_w, float* dW, float* db, int B, int S, int C, hipStream_t s) {
     hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 64)), dim3(1024), 0, s, partial_w, final_reduce_rows(B, S), C * 9 + 1, dW, C * 9, db);
 }
-void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* W, const void* y, void* dy, int B, int S, int C, float* bn,
+void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* Wt, const void* y, void* dy, int B, int S, int C, float* bn,
                                const float* partial, float* dgamma, float* dbeta, hipStream_t s) {
     const int nstrips = B * (S / 4) * (S / 32), nch = final_reduce_rows(B, S);
     const float* p0 = partial; const float* p1 = partial + (size_t)nch * C;
     launch_bn_bwd_fin(p0, p1, nch, (int64_t)B * S * S, C, bn, dgamma, dbeta, 0, s);
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_bnbwd_apply<T>, dim3(nstrips), dim3(256), 0, s, dpre, W, (const T*)y, bn, (T*)dy, S));
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_bnbwd_apply<T>, dim3(nstrips), dim3(256), 0, s, dpre, Wt, (const T*)y, bn, (T*)dy, S));
 }
 
 // =========================================================================================
@@ -938,7 +934,7 @@ void launch_conv1_wgrad(int dt, const void* dv, const float* x0, int n0, const f
 // every tap exactly once (ih = 2a: kh 1 -> oh a, kh 3 -> oh a-1; ih = 2a+1: kh 0 -> oh a+1, kh 2 -> oh a).
 // 16 channel lanes x 16 columns per block, RA block rows per thread (sliding 3-row window).
 template <class T, int RA>
-__global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const T* __restrict__ dv, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const T* __restrict__ dv, const float* __restrict__ Wt,
                                                           const float* __restrict__ img, float* __restrict__ dpre, int S) {
     constexpr int C = 64;
     const int Ho = S >> 1, nbb = Ho >> 4, nba = Ho / RA;
@@ -946,12 +942,9 @@ __global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const T* __restrict__ 
     int bid = blockIdx.x;
     const int b = (bid % nbb) * 16 + bl; bid /= nbb;
     const int a0 = (bid % nba) * RA, n = bid / nba;
-    __shared__ __attribute__((aligned(16))) float sw[16 * (C + 4)];  // W[co][tap] -> [tap][co] (row stride C + 4), one coalesced pass
-    for (int i = threadIdx.x; i < 16 * C; i += 256) sw[(i & 15) * (C + 4) + (i >> 4)] = W[i];
-    __syncthreads();
-    f4v w[16];
+    f4v w[16];                        // Wt = the weight as [tap][co] (k_prepare's PREP_TAPS copy): no LDS transpose, no barrier
 #pragma unroll
-    for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const f4v*>(sw + t * (C + 4) + q * 4);
+    for (int t = 0; t < 16; ++t) w[t] = ldg4(Wt + t * C + q * 4);
     const T* base = dv + (size_t)n * Ho * Ho * C + q * 4;
     f4v g[RA + 2][3];
 #pragma unroll
@@ -995,13 +988,13 @@ __global__ __launch_bounds__(256) void k_conv1_dgrad_tanh(const T* __restrict__ 
     }
 #undef DOT4
 }
-void launch_conv1_dgrad_tanh(int dt, const void* dv, const float* W, const float* img, float* dpre, int B, int S, int C,
+void launch_conv1_dgrad_tanh(int dt, const void* dv, const float* Wt, const float* img, float* dpre, int B, int S, int C,
                              hipStream_t s) {
     (void)C;
     const int Ho = S / 2;
     SIGGAN_DT_SWITCH(dt, T, {
         // two block rows per thread: 118 registers, four waves per SIMD (four rows: 142 / three; 13.2 -> 12.0 us)
-        hipLaunchKernelGGL((k_conv1_dgrad_tanh<T, 2>), dim3(B * (Ho / 2) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, W, img, dpre, S);
+        hipLaunchKernelGGL((k_conv1_dgrad_tanh<T, 2>), dim3(B * (Ho / 2) * (Ho / 16)), dim3(256), 0, s, (const T*)dv, Wt, img, dpre, S);
     });
 }
 

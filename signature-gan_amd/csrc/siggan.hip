@@ -156,7 +156,7 @@ struct siggan_ctx {
     float *logits, *probs, *dlogit;
     char *g_up[MAXL + 1], *g_dn[MAXL + 1], *d_dn[MAXL + 1], *d_up[MAXL + 1];
     float *wcp;
-    float *slab, *slab_k, *slab_k2, *slab_k3, *partial, *partial_b, *partial_c, *z_g, *img_g, *metrics, *zeros, *wfc_t, *real_stage, *mask_stage;
+    float *slab, *slab_k, *slab_k2, *slab_k3, *partial, *partial_b, *partial_c, *z_g, *img_g, *metrics, *zeros, *wfc_t, *wfin_t, *d_w1t, *real_stage, *mask_stage;
     char *op_pack;
     int64_t slab_floats, slab_k_floats;
     DevState* dev;
@@ -347,6 +347,8 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve_t(&c->op_pack, (int64_t)512 * 512 * 16);
         carve(&c->zeros, 64);
         carve(&c->wfc_t, (int64_t)c->F * c->latent);
+        carve(&c->wfin_t, (int64_t)9 * c->gC[c->Lg]);
+        carve(&c->d_w1t, (int64_t)16 * c->dC[1]);
         float* devp = nullptr;
         carve(&devp, 64);
         if (pass == 1) c->dev = (DevState*)devp;
@@ -540,6 +542,9 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
             j.dst = c->g_bne[l];
             prep_add(t, j, C);
         }
+        memset(&j, 0, sizeof j);                                       // final conv: [tap][c] for the strip kernels
+        j.type = PREP_TAPS; j.I = 9; j.O = c->gC[c->Lg]; j.src = GP(c, gi_fin_w(c)); j.dst = c->wfin_t;
+        prep_add(t, j, 9 * j.O);
         if (!launch_prepare(t, BN_EPS, sg)) c->lane_err = hipErrorInvalidValue;   // table overflow: reported by the caller
     }
     if (do_d) {
@@ -565,6 +570,10 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
             j.mul = c->sn_sig + (sn_slot * 2 + 1) * SnTable::MAXS;
             prep_add(t, j, j.O);
         }
+        memset(&j, 0, sizeof j);                                       // block 1 as [tap][co] for its input-gradient kernel
+        j.type = PREP_TAPS; j.I = 16; j.O = c->dC[1]; j.src = DP(c, di_w(1)); j.dst = c->d_w1t;
+        if (c->sn) j.mul = c->sn_sig + (sn_slot * 2 + 1) * SnTable::MAXS;
+        prep_add(t, j, j.O * 16);
         if (!launch_prepare(t, BN_EPS, sd)) c->lane_err = hipErrorInvalidValue;
     }
 }
@@ -655,9 +664,9 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
         }
     }
     if (training)
-        launch_final_fwd(c->dt, c->g_y[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s, c->g_bn[c->Lg]);
+        launch_final_fwd(c->dt, c->g_y[c->Lg], c->wfin_t, GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s, c->g_bn[c->Lg]);
     else
-        launch_final_fwd(c->dt, A[c->Lg], GP(c, gi_fin_w(c)), GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
+        launch_final_fwd(c->dt, A[c->Lg], c->wfin_t, GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
     c->ga_last_B = training ? B : 0;
 }
 
@@ -700,7 +709,6 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
     auto act = [&](int l) { const int64_t H = c->S >> l; return c->d_a[l] + (size_t)((int64_t)r0 * H * H * c->dC[l]) * c->es; };
     auto dvp = [&](int l) { const int64_t H = c->S >> l; return c->d_dv[l] + (size_t)((int64_t)r0 * H * H * c->dC[l]) * c->es; };
     auto nz = [&](int l) { return dropout ? c->d_noise[l] + (int64_t)r0 * c->dC[l] : nullptr; };
-    const float* const w1 = c->sn ? c->d_w1s : DP(c, di_w(1));
     // sigmoid + BCE: losses / means into the metrics, d(logit) for the classifier's weight gradient -- on lane b; the
     // chain below recomputes d(logit) from the logits and does not wait for it
     // Lanes: an event record on the main lane delays the kernel behind it by ~6 us and a join whose event
@@ -768,7 +776,7 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
         L.join(L.b);
     }
     if (want_dimage)
-        launch_conv1_dgrad_tanh(c->dt, dvp(1), w1, x0, c->dpre, Bd, c->S, c->dC[1], L.m);
+        launch_conv1_dgrad_tanh(c->dt, dvp(1), c->d_w1t, x0, c->dpre, Bd, c->S, c->dC[1], L.m);
 }
 
 // Backward through the Generator from d(pre-tanh) in c->dpre; fills the G gradient arena.  Lane m:
@@ -780,9 +788,9 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
         const int64_t R = (int64_t)B * Ho * Ho;
         if (l == Lg) {   // final conv's input-gradient folded into this block's BatchNorm backward; its weight gradient rides in
                          // the same pass over y and its row sums stay on this lane (a 5 us kernel does not pay for a fork + join)
-            launch_final_bwd_reduce(c->dt, c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b, L.m);
+            launch_final_bwd_reduce(c->dt, c->dpre, c->wfin_t, c->g_y[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b, L.m);
             launch_final_wgrad_fin(c->partial_b, GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), B, S, Co, L.m);
-            launch_final_bn_bwd_apply(c->dt, c->dpre, GP(c, gi_fin_w(c)), c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
+            launch_final_bn_bwd_apply(c->dt, c->dpre, c->wfin_t, c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
                                       GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
         } else
             launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m);
