@@ -17,7 +17,8 @@ import inputs as I                                   # noqa: E402  (tests/golden
 from oracle import siggan_oracle as O                # noqa: E402  (the checker)
 
 GOLDEN = os.path.join(HERE, "golden")
-CASES = [(64, 100, 4), (64, 100, 64), (128, 128, 4), (128, 128, 32), (64, 100, 128)]   # last: BASELINE configs[3] (batch 128)
+CASES = [(64, 100, 4), (64, 100, 64), (128, 128, 4), (128, 128, 32), (64, 100, 128),   # (64, 100, 128): BASELINE configs[3]
+         (64, 100, 5)]      # an odd batch: ragged row tiles in every GEMM, five samples per BatchNorm statistic
 SEED = dict(state_g=101, state_d=202, adam_g=303, adam_d=404, z=11, real=22)
 
 

@@ -29,18 +29,18 @@ from common import I, O, SEED, d_chans, oracle_states
 
 pytestmark = pytest.mark.gpu
 
-CASES = [(64, 100, 4), (64, 100, 64), (128, 128, 32)]
+CASES = [(64, 100, 4), (64, 100, 64), (128, 128, 32), (64, 100, 5)]      # last: an odd batch (ragged row tiles)
 TORCH_T = {"bf16": torch.bfloat16, "f16": torch.float16}
 # metric: relative (losses, mean predictions); image: absolute (pixels in [-1, 1]); grad_t: relative L2 error of the worst
 # parameter tensor (NAMED in the report: it is final_conv.0.bias -- one scalar, a near-cancelling sum over every pixel -- at
 # the large cases, a bias / fc weight at the small ones); grad_all: relative L2 error of the whole gradient arena; bn: BatchNorm
 # running statistics, relative to scale.
-# (1) vs the fp32 oracle, free-running: 1.6 x the largest value measured on the MI355X over the three cases
-# (profiles/r03_narrow_parity.json: bf16 metric 1.02e-2, image 4.7e-3, grad_t 0.259, grad_all 0.130, bn 7e-4; f16 7e-4, 6e-4,
+# (1) vs the fp32 oracle, free-running: 1.6 x the largest value measured on the MI355X over the four cases
+# (profiles/r03_narrow_parity.json: bf16 metric 1.02e-2, image 4.7e-3, grad_t 0.259, grad_all 0.130, bn 8.9e-4 -- the five-sample batch; f16 7e-4, 6e-4,
 # 0.0945, 0.0463, 1e-4).  Forward quantities track the storage precision (8x between the types); the gradients are ~2.7x apart:
 # they are dominated by what 16-bit operands do to heavily cancelling sums, activation storage and weight copies alike, and
 # NOT by the stored activation gradients (profiles/bf16_rounding_sites.py).
-TOL_FP32 = {"bf16": dict(metric=1.6e-2, image=7.5e-3, grad_t=0.42, grad_all=0.21, bn=1.2e-3),
+TOL_FP32 = {"bf16": dict(metric=1.6e-2, image=7.5e-3, grad_t=0.42, grad_all=0.21, bn=1.45e-3),
             "f16": dict(metric=1.2e-3, image=1e-3, grad_t=0.15, grad_all=0.075, bn=1.6e-4)}
 # (2) vs the storage-rounding oracle with shared sign decisions: 8x apart, as the precisions are.
 # (bn: ONE pre-BatchNorm element that rounds the other way moves a 4-sample feature variance by ~1 ulp / 4: the bound is one
