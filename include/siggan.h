@@ -173,7 +173,11 @@ int siggan_set_step_variant(siggan_ctx *ctx, int32_t variant);
 
 /* ---- forward passes ---------------------------------------------------------------------- */
 /* z_dev (B,latent) -> images_dev (B,1,S,S) in [-1,1].  training!=0: BatchNorm batch statistics,
- * running stats and num_batches_tracked updated (nn.Module.train()); 0: running stats (eval). */
+ * running stats and num_batches_tracked updated (nn.Module.train()); 0: running stats (eval).
+ * A training-mode Generator forward of ONE sample is refused with SIGGAN_E_INVALID and torch's text ("Expected more than 1
+ * value per channel when training ...": the fc block's BatchNorm1d, generator_vanilla_gan.py:112) -- here, in siggan_g_grads
+ * and in the ablation variant's siggan_d_grads; the trainer variant's D step accepts one sample (G.eval(), no BatchNorm in D),
+ * and siggan_step_begin then does not start the Generator forward ahead of the siggan_g_grads that refuses it. */
 int siggan_g_forward(siggan_ctx *ctx, const float *z_dev, int32_t batch, int32_t training,
                      float *images_dev, void *stream);
 

@@ -507,6 +507,14 @@ extern "C" int siggan_rng_state(siggan_ctx* c, uint64_t* seed, uint64_t* offset)
 // ------------------------------------------------------------------------------------------
 // internal passes
 // ------------------------------------------------------------------------------------------
+// A training-mode Generator forward of ONE sample: the fc block's BatchNorm1d has a single value per channel, which torch
+// refuses (torch/nn/functional.py _verify_batch_size, reached from generator_vanilla_gan.py:112) -- same refusal, same text
+// (the binding raises ValueError for SIGGAN_E_INVALID, as torch does).  Eval mode and the Discriminator take one sample.
+static int check_bn_batch(const siggan_ctx* c, int batch) {
+    if (batch == 1)
+        return fail(SIGGAN_E_INVALID, "Expected more than 1 value per channel when training, got input size torch.Size([1, %d])", c->F);
+    return SIGGAN_OK;
+}
 static int check_call(siggan_ctx* c, int batch, bool need_bound = true) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     if (need_bound && !c->bound) return fail(SIGGAN_E_STATE, "siggan_bind has not been called");
@@ -1160,6 +1168,7 @@ extern "C" int siggan_g_forward(siggan_ctx* c, const float* z_dev, int32_t batch
     ENTER(c);
     int rc = check_call(c, batch);
     if (rc) return rc;
+    if (training && (rc = check_bn_batch(c, batch))) return rc;
     if (!z_dev || !images_dev) return fail(SIGGAN_E_INVALID, "null tensor");
     hipStream_t s = (hipStream_t)stream;
     if ((rc = settle(c, s))) return rc;
@@ -1210,7 +1219,10 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     // pipelined Generator forward -- siggan_g_grads then runs the training forward itself (an explicit zg_dev waits in
     // z_g, zg_stash)
     if (c->sn && !abl) spec_g = false;
+    // one sample: the reference's D step runs (G.eval()) and its G step then refuses the batch -- no forward ahead of that
+    if (batch == 1 && !abl) spec_g = false;
     if (abl) {                                 // one z per iteration: it belongs to the (single, training-mode) Generator forward
+        if ((rc = check_bn_batch(c, batch))) return rc;
         if (zg_dev) return fail(SIGGAN_E_INVALID, "the ablation step has one latent batch per iteration: pass it as z_dev");
         zg_dev = z_dev; z_dev = nullptr; spec_g = true;
     }
@@ -1323,6 +1335,7 @@ extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, 
     ENTER(c);
     int rc = check_call(c, batch);
     if (rc) return rc;
+    if ((rc = check_bn_batch(c, batch))) return rc;
     if ((rc = check_hyper(hp))) return rc;
     if (!c->st.g_grads) return fail(SIGGAN_E_STATE, "gradient arena was not bound");
     hipStream_t s = (hipStream_t)stream;

@@ -373,6 +373,33 @@ def test_latent_drawn_inside_the_fc_kernel():
     e1.close(); e2.close()
 
 
+def test_one_sample_is_refused_where_torch_refuses_it():
+    """generator_vanilla_gan.py:112: the fc block's BatchNorm1d in training mode refuses a batch of one ("Expected more than
+    1 value per channel when training", a ValueError).  Same refusal, same exception type, at the same point of a step: the
+    D step of a one-sample batch runs (G.eval(), no BatchNorm in D), the G step raises and leaves the Generator untouched;
+    eval-mode generation and scoring of a single image work."""
+    from hipcommon import cuda, make_engine
+    size, latent = 64, 100
+    eng = make_engine(size, latent, 4, warm=True)
+    eng.seed(5)
+    z = cuda(torch.randn(1, latent, generator=torch.Generator().manual_seed(1)))
+    real = cuda(torch.from_numpy(I.gen_real(1, size, SEED["real"])))
+    img = eng.g_forward(z, training=False)
+    assert tuple(img.shape) == (1, 1, size, size) and torch.isfinite(img).all()
+    assert torch.isfinite(eng.d_forward(real, training=False)).all()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        eng.g_forward(z, training=True)
+    g_before, d_before = eng.g_params.clone(), eng.d_params.clone()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        eng.train_step(real, clip=0.5)                                    # D half done, G half refused (train...py:309-360)
+    assert torch.equal(eng.g_params, g_before) and not torch.equal(eng.d_params, d_before)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        eng.g_step(1)
+    met = eng.d_step(real, clip=0.5)                                      # the context is still usable
+    assert all(v == v for v in met.values() if isinstance(v, float))
+    eng.close()
+
+
 def test_abandoned_staged_forward_is_ordered():
     """A D(real) forward started ahead of time (siggan_stage_real) that no D step consumes must not race with what
     follows: a Discriminator forward on other images right behind the step, then a step on a DIFFERENT batch, give
