@@ -594,19 +594,24 @@ void launch_final_fwd(int dt, const void* act, const float* Wt, const float* b, 
 // The activation gradient is never stored: BatchNorm's backward of the last Generator block needs it
 // twice (statistics, then apply) and recomputing it from the 1-channel dpre is 36 FMAs against a
 // 33 MB round trip.  d[r][k] = dpre row (y0 - 1 + r), column (x - 1 + k), zero outside the image.
+// The strip's dpre neighbourhood -- (RY + 2) rows x 34 columns of a one-channel image, zero outside it -- goes through LDS:
+// one element per thread, one coalesced load each (the eight channel lanes of a pixel used to load the same 18 scalars, and
+// hipcc turned the row-validity tests -- uniform per strip -- into branches with a vmcnt(0) behind each: twelve dependent
+// round trips in front of the strip's arithmetic).
 template <int RY>
-__device__ __forceinline__ void load_dpre_strip(const float* __restrict__ dpre, const StripId& t, int S, float (&d)[RY + 2][3]) {
-    const float* base = dpre + (size_t)t.n * S * S;
+__device__ __forceinline__ float dpre_patch_elem(const float* __restrict__ dpre, int n, int y0, int xb, int S, int idx) {
+    constexpr int PW = 34;
+    const int r = idx / PW, k = idx - r * PW;
+    const int yy = y0 + r - 1, xx = xb + k - 1, yc = clampi(yy, S - 1), xc = clampi(xx, S - 1);
+    const float q = dpre[((size_t)n * S + yc) * S + xc];
+    return (yy == yc && xx == xc && idx < (RY + 2) * PW) ? q : 0.f;
+}
+template <int RY>
+__device__ __forceinline__ void read_dpre_patch(const float* sp, int xi, float (&d)[RY + 2][3]) {
 #pragma unroll
-    for (int r = 0; r < RY + 2; ++r) {
-        const int yy = t.y0 + r - 1, yc = clampi(yy, S - 1);
+    for (int r = 0; r < RY + 2; ++r)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int xx = t.x + k - 1, xc = clampi(xx, S - 1);
-            const float q = base[yc * S + xc];
-            d[r][k] = (yy == yc && xx == xc) ? q : 0.f;
-        }
-    }
+        for (int k = 0; k < 3; ++k) d[r][k] = sp[r * 34 + xi + k];
 }
 template <int RY>
 __device__ __forceinline__ f4v final_dact(const float (&d)[RY + 2][3], const f4v (&w)[9], int r) {
@@ -651,27 +656,34 @@ __global__ __launch_bounds__(256) void k_final_bwd_reduce(const float* __restric
     float sdb = 0.f;
     // the y rows of the NEXT strip are requested before the current strip is reduced (a block walks several strips when the
     // launcher caps the grid): the loads of strip i+1 fly under the ~300 FMAs per row of strip i
+    __shared__ float sp[2][(RY + 2) * 34];
+    const int xi = threadIdx.x >> 3;
     f4v yn[RY];
+    float pn;                                  // this thread's element of the next strip's dpre patch
     {
-        const StripId t0 = strip_of<RY>(blockIdx.x < (unsigned)nstrips ? blockIdx.x : 0, S, threadIdx.x >> 3);
+        const StripId t0 = strip_of<RY>(blockIdx.x < (unsigned)nstrips ? blockIdx.x : 0, S, xi);
         const T* yb = y + (((size_t)t0.n * S + t0.y0) * S + t0.x) * C + c4 * 4;
 #pragma unroll
         for (int r = 0; r < RY; ++r) yn[r] = ld4<T>(yb + (size_t)r * S * C);
+        pn = dpre_patch_elem<RY>(dpre, t0.n, t0.y0, t0.x - xi, S, threadIdx.x);
     }
-    for (int sid = blockIdx.x; sid < nstrips; sid += gridDim.x) {
-        const StripId t = strip_of<RY>(sid, S, threadIdx.x >> 3);
-        float d[RY + 2][3];
-        load_dpre_strip<RY>(dpre, t, S, d);
+    int it = 0;
+    for (int sid = blockIdx.x; sid < nstrips; sid += gridDim.x, it ^= 1) {
+        if (threadIdx.x < (RY + 2) * 34) sp[it][threadIdx.x] = pn;
+        __syncthreads();                       // (buffers alternate: the strip before last is read out by every thread by now)
         f4v yv[RY];
 #pragma unroll
         for (int r = 0; r < RY; ++r) yv[r] = yn[r];
         {
             const int nx = sid + gridDim.x < nstrips ? sid + gridDim.x : sid;
-            const StripId tn = strip_of<RY>(nx, S, threadIdx.x >> 3);
+            const StripId tn = strip_of<RY>(nx, S, xi);
             const T* yb = y + (((size_t)tn.n * S + tn.y0) * S + tn.x) * C + c4 * 4;
 #pragma unroll
             for (int r = 0; r < RY; ++r) yn[r] = ld4<T>(yb + (size_t)r * S * C);
+            pn = dpre_patch_elem<RY>(dpre, tn.n, tn.y0, tn.x - xi, S, threadIdx.x);
         }
+        float d[RY + 2][3];
+        read_dpre_patch<RY>(sp[it], xi, d);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             const f4v g = final_dact<RY>(d, w, r);
@@ -739,12 +751,17 @@ __global__ __launch_bounds__(256) void k_final_bnbwd_apply(const float* __restri
     for (int k = 0; k < 9; ++k) w[k] = ldg4(Wt + k * 32 + c4 * 4);
     const f4v sc = ldg4(bn + c4 * 4), sf = ldg4(bn + C + c4 * 4), mu = ldg4(bn + 2 * C + c4 * 4), rs = ldg4(bn + 3 * C + c4 * 4);
     const f4v c1 = ldg4(bn + 4 * C + c4 * 4), c2 = ldg4(bn + 5 * C + c4 * 4);
-    float d[RY + 2][3];
-    load_dpre_strip<RY>(dpre, t, S, d);
+    __shared__ float sp[(RY + 2) * 34];
+    const int xi = threadIdx.x >> 3;
+    const float pe = dpre_patch_elem<RY>(dpre, t.n, t.y0, t.x - xi, S, threadIdx.x);
     const size_t o0 = (((size_t)t.n * S + t.y0) * S + t.x) * C + c4 * 4;
     f4v yv[RY];
 #pragma unroll
     for (int r = 0; r < RY; ++r) yv[r] = ld4<T>(y + o0 + (size_t)r * S * C);
+    if (threadIdx.x < (RY + 2) * 34) sp[threadIdx.x] = pe;
+    __syncthreads();
+    float d[RY + 2][3];
+    read_dpre_patch<RY>(sp, xi, d);
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
         const f4v g = final_dact<RY>(d, w, r);
