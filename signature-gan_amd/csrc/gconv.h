@@ -15,6 +15,10 @@ enum Epilogue : int {
     EPI_BIAS_LRELU_DROP,  // leaky(acc + bias[c]) * noise[n,c]         (Discriminator block forward)
     EPI_AFFINE_RELU,      // relu(acc * scale[c] + shift[c])           (Generator block, BN eval folded)
     EPI_LRELU_BWD,        // acc * leaky'(aref) * noise[n,c]           (Discriminator input-gradient)
+    EPI_BN_BWD_STATS,     // store the accumulator AND the BatchNorm-backward sums of the tensor it is the gradient of (Generator
+                          // input-gradient): per workgroup one partial row of sum(dr) and sum(dr * xhat), dr = relu'(.) * acc with
+                          // the mask re-derived from aref = the pre-BatchNorm tensor y (fma(y, scale, shift) > 0, k_bn_relu's own
+                          // expression) and xhat = (y - mean) * rstd -- what k_colreduce<FBnBwd> computes in a pass of its own
 };
 
 // out[n, opix, co] = sum_{tap, ci} in[n, pix(tap), ci] * wp[cls][co][tap*Ci + ci]
@@ -33,7 +37,10 @@ struct GConvArgs {
     const float* noise;   // [B][Co] dropout multipliers (0 or 1/(1-p)); nullptr = none
     const float* scale;   // [Co]
     const float* shift;   // [Co]
-    const void* aref;     // [B][Ho][Wo][Co] stored activation (EPI_LRELU_BWD)
+    const void* aref;     // [B][Ho][Wo][Co] stored activation (EPI_LRELU_BWD) / pre-BatchNorm tensor (EPI_BN_BWD_STATS)
+    const float* bnp;     // EPI_BN_BWD_STATS: [scale | shift | mean | rstd] of the output's BatchNorm, Co floats each
+    float* stat0;         // EPI_BN_BWD_STATS: partial rows [nrows][Co] of sum(dr); launch_gconv returns nrows and puts the
+    float* stat1;         //   rows of sum(dr * xhat) right behind them (stat1 = stat0 + nrows * Co, filled by launch_gconv)
     float slope;
     // split-K scratch (optional): nsplit fp32 slabs of the whole output, summed by k_splitk_epilogue
     float* slab;
@@ -41,6 +48,26 @@ struct GConvArgs {
     size_t slab_stride;   // filled by launch_gconv
     const float* zeros;   // >= 16 bytes of zeros (source of out-of-image taps)
 };
+
+// EPI_BN_BWD_STATS, one float4 of the output: v = the accumulator as it is stored (rounded to T), y = the pre-BatchNorm values
+// at the same place; the arithmetic is k_colreduce<FBnBwd>'s, element for element.
+struct BnBwdParams { f32x4 sc, sf, mu, rs; };
+__device__ __forceinline__ BnBwdParams bn_bwd_params(const float* __restrict__ bnp, int Co, int co) {
+    BnBwdParams q;
+    q.sc = *reinterpret_cast<const f32x4*>(bnp + co); q.sf = *reinterpret_cast<const f32x4*>(bnp + Co + co);
+    q.mu = *reinterpret_cast<const f32x4*>(bnp + 2 * Co + co); q.rs = *reinterpret_cast<const f32x4*>(bnp + 3 * Co + co);
+    return q;
+}
+template <class T>
+__device__ __forceinline__ void bn_bwd_stat_terms(const f32x4 v, const f32x4 y, const BnBwdParams& q, f32x4& s0, f32x4& s1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float vq = (float)(T)v[e];
+        const float d = fmaf(y[e], q.sc[e], q.sf[e]) > 0.f ? vq : 0.f;
+        s0[e] += d;
+        s1[e] = fmaf(d, (y[e] - q.mu[e]) * q.rs[e], s1[e]);
+    }
+}
 
 // slab[z][i][tap*Cl + l] = sum_{pix in split z} S[pix][i] * L[n, 2p-1+kh, 2q-1+kw][l]
 struct WgradArgs {
@@ -74,7 +101,8 @@ extern Prof* g_prof;
 // GPU box inside one process image; every switch is removed, or becomes the rule, once measured)
 int exp_knob(const char* name, int dflt);
 
-void launch_gconv(const GConvArgs& a, hipStream_t st);
+// returns the number of partial rows written to stat0 / stat1 (EPI_BN_BWD_STATS), 0 otherwise
+int launch_gconv(const GConvArgs& a, hipStream_t st);
 // 16-bit operand kernels (gconv16.hip); cfg: 0 = 128x128, 2 = 64x64, 3 = 128x32 tiles; e0 / e1: optional timing events
 void launch_gconv16(int cfg, const GConvArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int kq = 1);
 void launch_wgrad16(bool small, const WgradArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1);

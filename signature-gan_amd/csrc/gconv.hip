@@ -283,10 +283,13 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv(const GConvArgs a) {
                     sT[(wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDT + wn * (32 * TN) + 32 * j + li] = acc[i][j][r];
     }
     __syncthreads();
-    if (quad != 0) return;
+    if (quad != 0 && epi != EPI_BN_BWD_STATS) return;       // (with the statistics every wave stays for the barriers below)
     constexpr int C4 = BN / 4, RPP = 256 / C4;       // float4 columns per row, rows per pass
     const int c4 = tid % C4, r0 = tid / C4;
     const int co = n0 + c4 * 4;
+    BnBwdParams bq;
+    f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = st0;
+    if (epi == EPI_BN_BWD_STATS) bq = bn_bwd_params(a.bnp, a.Co, co);
     const f32x4 bias4 = epi == EPI_BIAS_LRELU_DROP ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
     if (epi == EPI_AFFINE_RELU) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + co); sh4 = *reinterpret_cast<const f32x4*>(a.shift + co); }
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv(const GConvArgs a) {
 #pragma unroll
     for (int p = 0; p < BM / RPP; ++p) {
         const int row = r0 + RPP * p, m = m0 + row;
-        if (m >= a.M) continue;
+        if (m >= a.M || quad != 0) continue;
         const int n = m >> (a.lgHr + a.lgWr);
         size_t opix;
         if (a.form == 0) {
@@ -305,7 +308,9 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv(const GConvArgs a) {
         }
         const size_t o = opix * a.Co + co;
         f32x4 v = *reinterpret_cast<const f32x4*>(sT + row * LDT + c4 * 4);
-        if (epi == EPI_BIAS_LRELU_DROP) {
+        if (epi == EPI_BN_BWD_STATS) {
+            bn_bwd_stat_terms<float>(v, *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.aref) + o), bq, st0, st1);
+        } else if (epi == EPI_BIAS_LRELU_DROP) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { float t = v[e] + bias4[e]; v[e] = t > 0.f ? t : t * a.slope; }
             if (use_noise) {
@@ -327,6 +332,26 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv(const GConvArgs a) {
             }
         }
         *reinterpret_cast<f32x4*>(outp + o) = v;
+    }
+    if (epi == EPI_BN_BWD_STATS) {
+        // the tile's column sums: the RPP row lanes of a channel group meet in LDS (the tile is stored: sT is free after the
+        // barrier) and are added in lane order -- one partial row per workgroup, a fixed sum order
+        __syncthreads();
+        if (quad == 0) {
+            *reinterpret_cast<f32x4*>(sT + (size_t)tid * 8) = st0;
+            *reinterpret_cast<f32x4*>(sT + (size_t)tid * 8 + 4) = st1;
+        }
+        __syncthreads();
+        if (quad == 0 && r0 == 0) {
+#pragma unroll 4
+            for (int k = 1; k < RPP; ++k) {
+                st0 += *reinterpret_cast<const f32x4*>(sT + (size_t)(k * C4 + c4) * 8);
+                st1 += *reinterpret_cast<const f32x4*>(sT + (size_t)(k * C4 + c4) * 8 + 4);
+            }
+            const size_t prow = (size_t)cls * (gridDim.x / tiles_n) + bid / tiles_n;
+            *reinterpret_cast<f32x4*>(a.stat0 + prow * a.Co + co) = st0;
+            *reinterpret_cast<f32x4*>(a.stat1 + prow * a.Co + co) = st1;
+        }
     }
 }
 
@@ -481,6 +506,33 @@ __global__ __launch_bounds__(256) void k_gconv_up4(const GConvArgs a) {
 template <class T>
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int nsplit, int64_t total4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a.epi == EPI_BN_BWD_STATS) {
+        // 256 consecutive float4 = 256 / C4 rows of all C4 channel groups (launch_gconv checks C4 | 256): the row lanes of a
+        // group meet in LDS, one partial row per workgroup, a fixed sum order
+        __shared__ __attribute__((aligned(16))) float sh[256 * 8];
+        const int C4 = a.Co / 4, c4 = threadIdx.x & (C4 - 1);
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        if (i < total4) {
+            const f32x4* sl = reinterpret_cast<const f32x4*>(a.slab);
+            const size_t stride4 = a.slab_stride / 4;
+            f32x4 v = sl[i];
+            for (int z = 1; z < nsplit; ++z) v += sl[(size_t)z * stride4 + i];
+            bn_bwd_stat_terms<T>(v, ld4<T>(static_cast<const T*>(a.aref) + i * 4), bn_bwd_params(a.bnp, a.Co, c4 * 4), s0, s1);
+            st4<T>(static_cast<T*>(a.out) + i * 4, v);
+        }
+        *reinterpret_cast<f32x4*>(sh + threadIdx.x * 8) = s0;
+        *reinterpret_cast<f32x4*>(sh + threadIdx.x * 8 + 4) = s1;
+        __syncthreads();
+        if ((int)threadIdx.x < C4) {
+            for (int k = 1; k < 256 / C4; ++k) {
+                s0 += *reinterpret_cast<const f32x4*>(sh + (k * C4 + c4) * 8);
+                s1 += *reinterpret_cast<const f32x4*>(sh + (k * C4 + c4) * 8 + 4);
+            }
+            *reinterpret_cast<f32x4*>(a.stat0 + (size_t)blockIdx.x * a.Co + c4 * 4) = s0;
+            *reinterpret_cast<f32x4*>(a.stat1 + (size_t)blockIdx.x * a.Co + c4 * 4) = s1;
+        }
+        return;
+    }
     if (i >= total4) return;
     const float4* sl = reinterpret_cast<const float4*>(a.slab);
     const size_t stride4 = a.slab_stride / 4;
@@ -562,9 +614,18 @@ static double wgrad_bytes(const WgradArgs& a) {
 }
 
 template <int BM, int BN, int WM, int WN, int BKT = 32, int DEEP = 0, int KQ = 1>
-static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
+static int launch_cfg(const GConvArgs& a_in, hipStream_t st, int id, int nsplit) {
+    GConvArgs a = a_in;
     const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
     const int ncls = a.form == 0 ? 1 : 4;
+    const int64_t total4 = (int64_t)a.B * a.Ho * a.Wo * a.Co / 4;
+    int rows = 0;
+    if (a.epi == EPI_BN_BWD_STATS) {
+        // one partial row per workgroup of whichever kernel runs the epilogue; k_splitk_epilogue needs whole rows per workgroup
+        if (nsplit > 1 && (256 % (a.Co / 4)) != 0) nsplit = 1;
+        rows = nsplit > 1 ? (int)((total4 + 255) / 256) : ((a.M + BM - 1) / BM) * ncls;
+        a.stat1 = a.stat0 + (size_t)rows * a.Co;
+    }
     dim3 grid(tiles, nsplit, ncls);
     // algorithmic FLOPs = 2 * M * Co * (taps * Ci) per class (== 2 * conv MACs, padding taps included)
     if (g_prof) g_prof->begin(id, 2.0 * a.M * a.Co * (double)((a.form == 0 ? 16 : 4) * a.Ci) * ncls, gconv_bytes(a), st);
@@ -576,13 +637,12 @@ static void launch_cfg(const GConvArgs& a, hipStream_t st, int id, int nsplit) {
     } else {
         hipLaunchKernelGGL((k_gconv<BM, BN, WM, WN, BKT, DEEP, KQ>), grid, dim3(256 * KQ), 0, st, a);
     }
-    if (nsplit > 1) {
-        const int64_t total4 = (int64_t)a.B * a.Ho * a.Wo * a.Co / 4;
+    if (nsplit > 1)
         SIGGAN_DT_SWITCH(a.dt, T, hipLaunchKernelGGL(k_splitk_epilogue<T>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a, nsplit, total4));
-    }
+    return rows;
 }
 
-void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
+int launch_gconv(const GConvArgs& a_in, hipStream_t st) {
     // Tile choice: the fp32 MFMA is slow enough that a 32x32 accumulator per wave already runs the
     // matrix pipe at full rate, so what matters is having >= 2 workgroups per CU (512 on the chip)
     // to cover each other's barrier / first-fragment bubbles.  Take the largest tile that still
@@ -623,7 +683,7 @@ void launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         hipEvent_t e0 = g_prof ? g_prof->recs.back().e0 : nullptr, e1 = g_prof ? g_prof->recs.back().e1 : nullptr;
         if (a.Ci == 32) hipExtLaunchKernelGGL(k_gconv_up4<32>, grid, dim3(256), 0, st, e0, e1, 0, a);
         else hipExtLaunchKernelGGL(k_gconv_up4<64>, grid, dim3(256), 0, st, e0, e1, 0, a);
-        return;
+        return 0;
     }
     const int ns = splits(blocks(128, 32));
     return launch_cfg<128, 32, 4, 1, 32, 1>(a, st, 3, ns);   // Co == 32

@@ -86,7 +86,7 @@ void launch_bn_relu(int dt, const void* y, void* a, int64_t R, int C, const floa
 // backward through relu(BN(y)): da (in) -> dy (in place); dgamma/dbeta (torch order) written.  The relu mask is
 // re-derived from y and the layer's scale/shift (the forward's own expression), so the activation is not read.
 void launch_bn_bwd(int dt, void* da, const void* y, int64_t R, int C, float* bn, float* partial,
-                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s);
+                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s, int pre_rows = 0);
 
 // final 3x3 conv (C->1) + tanh, and its backward pieces.  act: [B][S][S][C] NHWC, img [B][S][S].
 // bn != nullptr (training): `act` is the last block's PRE-BatchNorm tensor y and bn its [scale | shift] table -- the

@@ -363,15 +363,19 @@ __global__ void k_bn_bwd_apply(T* __restrict__ da, const T* __restrict__ y, int6
     st4<T>(da + i * 4, f32x4{o.x, o.y, o.z, o.w});
 }
 void launch_bn_bwd(int dt, void* dav, const void* yv, int64_t R, int C, float* bn, float* partial,
-                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s) {
+                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s, int pre_rows) {
+    // pre_rows > 0: the kernel that produced da left that many partial rows of both sums in `partial` (gconv's
+    // EPI_BN_BWD_STATS): no reduction pass over da and y
     const ColPlan pl = col_plan(R, C);
-    float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
+    const int nch = pre_rows > 0 ? pre_rows : pl.nch;
+    float* p0 = partial; float* p1 = partial + (size_t)nch * C;
     const int64_t n4 = R * C / 4;
     SIGGAN_DT_SWITCH(dt, T, {
         T* da = (T*)dav; const T* y = (const T*)yv;
-        hipLaunchKernelGGL((k_colreduce<FBnBwd<T>>), dim3(pl.cbx, pl.nch), dim3(256), 0, s,
-                           FBnBwd<T>{da, y, (const float4*)bn}, R, C, pl.cg, pl.rows, p0, p1);
-        launch_bn_bwd_fin(p0, p1, pl.nch, R, C, bn, dgamma, dbeta, perm_c0, s);
+        if (pre_rows <= 0)
+            hipLaunchKernelGGL((k_colreduce<FBnBwd<T>>), dim3(pl.cbx, pl.nch), dim3(256), 0, s,
+                               FBnBwd<T>{da, y, (const float4*)bn}, R, C, pl.cg, pl.rows, p0, p1);
+        launch_bn_bwd_fin(p0, p1, nch, R, C, bn, dgamma, dbeta, perm_c0, s);
         hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(cdiv(n4, 256)), dim3(256), 0, s, da, y, n4, C / 4, (const float4*)bn);
     });
 }

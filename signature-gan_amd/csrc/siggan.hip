@@ -791,6 +791,7 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
 // BatchNorm backward and the input-gradient chain; lane a: the weight gradients.
 static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     const int Lg = c->Lg, S = c->S;
+    int pre_rows = 0;              // partial rows of block l's BatchNorm-backward sums left by the input-gradient GEMM of block l+1
     for (int l = Lg; l >= 1; --l) {
         const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
         const int64_t R = (int64_t)B * Ho * Ho;
@@ -801,7 +802,7 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
             launch_final_bn_bwd_apply(c->dt, c->dpre, c->wfin_t, c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
                                       GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
         } else
-            launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m);
+            launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m, pre_rows);
         L.fork(L.a);                                       // dy[l] is complete on m here
         // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
         // (one fork per block; per two blocks measured the same, weight gradients on the main lane 2.5 % slower: DESIGN 4)
@@ -815,7 +816,10 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
         a.in = c->g_da[l]; a.wp = c->g_dn[l]; a.out = c->g_da[l - 1];
         a.B = B; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
-        launch_gconv(a, L.m);
+        if (l >= 2) {              // its output is d(relu output) of block l-1: that block's BatchNorm-backward sums ride in the epilogue
+            a.epi = EPI_BN_BWD_STATS; a.aref = c->g_y[l - 1]; a.bnp = c->g_bn[l - 1]; a.stat0 = c->partial;
+        }
+        pre_rows = launch_gconv(a, L.m);
     }
     if (!(c->fc_fused && launch_fc_bwd_fused(c->dt, c->g_da[0], c->fc_y, z, c->g_bn[0], GG(c, gi_fc_w()), GG(c, gi_fc_b()),
                                              GG(c, gi_bn0_w()), GG(c, gi_bn0_b()), B, c->latent, c->gC[0], L.m))) {
