@@ -95,13 +95,13 @@ void launch_final_fwd(int dt, const void* act, const float* Wt, const float* b, 
                       const float* bn = nullptr);
 // backward of the last Generator block from dpre.  (1) launch_final_bwd_reduce: ONE read of y gives the BatchNorm-backward sums
 // (d(act) of the final conv recomputed from dpre, never stored; relu mask re-derived from y) into `partial` AND the partial
-// rows of the final conv's weight / bias gradient (activation re-derived from y) into `partial_w`;  (2) launch_final_wgrad_fin:
-// dW / db from partial_w (any lane);  (3) launch_final_bn_bwd_apply: dgamma / dbeta + dy from `partial`
+// rows of the final conv's weight / bias gradient (activation re-derived from y) into `partial_w`;  (2) launch_final_bn_bwd_apply:
+// ONE finalizer launch (dW / db from partial_w, dgamma / dbeta and the two means from `partial`), then dy
 void launch_final_bwd_reduce(int dt, const float* dpre, const float* Wt, const void* y, int B, int S, int C, const float* bn,
                              float* partial, float* partial_w, hipStream_t s);
-void launch_final_wgrad_fin(const float* partial_w, float* dW, float* db, int B, int S, int C, hipStream_t s);
 void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* Wt, const void* y, void* dy, int B, int S, int C, float* bn,
-                               const float* partial, float* dgamma, float* dbeta, hipStream_t s);
+                               const float* partial, const float* partial_w, float* dW, float* db, float* dgamma, float* dbeta,
+                               hipStream_t s);
 
 // ---- Discriminator pieces -----------------------------------------------------------------
 // first block (Cin = 1): x = two segments (x0: n < n0, x1: the rest), out [B][S/2][S/2][C]

@@ -220,10 +220,10 @@ __global__ __launch_bounds__(256) void k_colreduce(F f, int64_t R, int C, int cg
 // the lanes in a fixed order (bitwise reproducible).
 template <int W = 64>
 __device__ __forceinline__ void gather2(const float* __restrict__ p0, const float* __restrict__ p1, int nch, int C,
-                                        float& s, float& q, float (*sh)[16][64]) {
+                                        float& s, float& q, float (*sh)[16][64], int bx = -1) {
     // W column lanes x (blockDim / W) row lanes; the LDS block is used as [2][blockDim / W][W]
     const int cl = threadIdx.x & (W - 1), rl = threadIdx.x / W, nl = blockDim.x / W;
-    const int c = blockIdx.x * W + cl;
+    const int c = (bx < 0 ? (int)blockIdx.x : bx) * W + cl;
     float* const s0 = &sh[0][0][0];
     float* const s1 = &sh[1][0][0];
     float a = 0.f, b = 0.f;
@@ -788,6 +788,30 @@ __global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ par
     if (threadIdx.x >= 64 || j >= width) return;
     if (j < n0) o0[j] = s; else o1[j - n0] = s;
 }
+// Both finalizers behind k_final_bwd_reduce in ONE launch (two independent 5 us kernels on the Generator backward's
+// critical lane): blocks [0, nbw) add the partial rows of the final conv's weight / bias gradient (k_rows_sum), the block
+// behind them finalizes the last block's BatchNorm-backward sums (k_bn_bwd_fin<32>).  Same sums, same order.
+__global__ __launch_bounds__(1024) void k_final_fin(const float* __restrict__ partial_w, int nch_w, int width, float* __restrict__ dW,
+                                                    int n0, float* __restrict__ db, int nbw, const float* __restrict__ p0,
+                                                    const float* __restrict__ p1, int nch, int64_t R, int C, float* __restrict__ bn,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sh[2][16][64];
+    float s, q;
+    if ((int)blockIdx.x < nbw) {
+        gather2(partial_w, nullptr, nch_w, width, s, q, sh);
+        const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+        if (threadIdx.x >= 64 || j >= width) return;
+        if (j < n0) dW[j] = s; else db[j - n0] = s;
+        return;
+    }
+    const int bx = blockIdx.x - nbw;
+    gather2<32>(p0, p1, nch, C, s, q, sh, bx);
+    const int c = bx * 32 + (threadIdx.x & 31);
+    if (threadIdx.x >= 32 || c >= C) return;
+    dbeta[c] = s; dgamma[c] = q;                       // (perm_c0 == 0: identity)
+    const float invR = 1.0f / (float)R;
+    bn[4 * C + c] = s * invR; bn[5 * C + c] = q * invR;
+}
 // rows per strip of k_final_bwd_reduce: 4 (8-row strips need 256 registers and measured 36 vs 26 us)
 constexpr int FINAL_RY = 4;
 // two workgroups of this kernel per CU (188-204 registers): 512 of them walk the strips, each requesting strip i+1's rows while
@@ -802,14 +826,14 @@ void launch_final_bwd_reduce(int dt, const float* dpre, const float* Wt, const v
     SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL((k_final_bwd_reduce<T, FINAL_RY>), dim3(nch), dim3(256), 0, s, dpre, Wt, (const T*)y, bn, p0, p1,
                                                 partial_w, S, nstrips));
 }
-void launch_final_wgrad_fin(const float* partial_w, float* dW, float* db, int B, int S, int C, hipStream_t s) {
-    hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 64)), dim3(1024), 0, s, partial_w, final_reduce_rows(B, S), C * 9 + 1, dW, C * 9, db);
-}
 void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* Wt, const void* y, void* dy, int B, int S, int C, float* bn,
-                               const float* partial, float* dgamma, float* dbeta, hipStream_t s) {
+                               const float* partial, const float* partial_w, float* dW, float* db, float* dgamma, float* dbeta,
+                               hipStream_t s) {
     const int nstrips = B * (S / 4) * (S / 32), nch = final_reduce_rows(B, S);
     const float* p0 = partial; const float* p1 = partial + (size_t)nch * C;
-    launch_bn_bwd_fin(p0, p1, nch, (int64_t)B * S * S, C, bn, dgamma, dbeta, 0, s);
+    const int nbw = cdiv(C * 9 + 1, 64);
+    hipLaunchKernelGGL(k_final_fin, dim3(nbw + cdiv(C, 32)), dim3(1024), 0, s, partial_w, nch, C * 9 + 1, dW, C * 9, db, nbw, p0, p1, nch,
+                       (int64_t)B * S * S, C, bn, dgamma, dbeta);
     SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_bnbwd_apply<T>, dim3(nstrips), dim3(256), 0, s, dpre, Wt, (const T*)y, bn, (T*)dy, S));
 }
 

@@ -798,9 +798,8 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
         if (l == Lg) {   // final conv's input-gradient folded into this block's BatchNorm backward; its weight gradient rides in
                          // the same pass over y and its row sums stay on this lane (a 5 us kernel does not pay for a fork + join)
             launch_final_bwd_reduce(c->dt, c->dpre, c->wfin_t, c->g_y[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b, L.m);
-            launch_final_wgrad_fin(c->partial_b, GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), B, S, Co, L.m);
-            launch_final_bn_bwd_apply(c->dt, c->dpre, c->wfin_t, c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial,
-                                      GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
+            launch_final_bn_bwd_apply(c->dt, c->dpre, c->wfin_t, c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b,
+                                      GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
         } else
             launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m, pre_rows);
         L.fork(L.a);                                       // dy[l] is complete on m here
