@@ -122,7 +122,8 @@ void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* p
 // dv[n][hw][c] = dlogit[n] * wcp[hw*C+c] * leaky'(act) * noise[n][c]
 // from the logits (rows < n0: target y0, the rest y1; each segment's mean): d(logit) is recomputed with k_bce's expression
 void launch_cls_bwd(int dt, const float* logits, int n0, float y0, float y1, const float* wcp, const void* act, const float* noise,
-                    float slope, void* dv, int B, int C, hipStream_t s, float gscale = 1.0f);
+                    float slope, void* dv, int B, int C, hipStream_t s, float gscale = 1.0f, float* bce_probs = nullptr,
+                    float* bce_dlogit = nullptr, float* bce_metrics = nullptr, int bce_is_g = 0, bool with_bce = false);
 // dWc (torch order c*16+hw) and dbc
 void launch_cls_wgrad(int dt, const float* dlogit, const void* act, float* dWc, float* dbc, int B, int C, hipStream_t s);
 // dst[i] = (float)src[i] for a tensor of element type dt

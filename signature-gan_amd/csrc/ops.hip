@@ -1089,10 +1089,10 @@ void launch_cls_features(int dt, const void* act, float* feat, int B, int C, hip
 __device__ __forceinline__ float bce_dlogit(float x, float y, float inv_count);
 // nn.Sigmoid + nn.BCELoss(mean) per segment and its gradient w.r.t. the logit (torch formulas:
 // log clamped at -100; grad_p = (p - y) / max((1 - p) * p, 1e-12) / count; dlogit = grad_p * p * (1 - p))
-__global__ __launch_bounds__(256) void k_bce(const float* __restrict__ logits, int B, int n0, float y0, float y1,
-                                             float* __restrict__ probs, float* __restrict__ dlogit,
-                                             float* __restrict__ metrics, int is_g, float gscale) {
-    __shared__ float sh[4];
+struct BceArgs { const float* logits; int B, n0; float y0, y1; float* probs; float* dlogit; float* metrics; int is_g; float gscale; };
+__device__ __forceinline__ void bce_block(const float* __restrict__ logits, int B, int n0, float y0, float y1,
+                                          float* __restrict__ probs, float* __restrict__ dlogit,
+                                          float* __restrict__ metrics, int is_g, float gscale, float* sh) {
     float l0 = 0.f, l1 = 0.f, p0 = 0.f, p1 = 0.f, a0 = 0.f, a1 = 0.f;
     const float c0 = 1.0f / (float)(n0 > 0 ? n0 : 1), c1 = 1.0f / (float)(B - n0 > 0 ? B - n0 : 1);
     for (int n = threadIdx.x; n < B; n += 256) {
@@ -1119,9 +1119,13 @@ __global__ __launch_bounds__(256) void k_bce(const float* __restrict__ logits, i
         }
     }
 }
+__global__ __launch_bounds__(256) void k_bce(const BceArgs b) {
+    __shared__ float sh[4];
+    bce_block(b.logits, b.B, b.n0, b.y0, b.y1, b.probs, b.dlogit, b.metrics, b.is_g, b.gscale, sh);
+}
 void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* probs, float* dlogit, float* metrics,
                 int is_g_step, hipStream_t s, float gscale) {
-    hipLaunchKernelGGL(k_bce, dim3(1), dim3(256), 0, s, logits, B, n0, y0, y1, probs, dlogit, metrics, is_g_step, gscale);
+    hipLaunchKernelGGL(k_bce, dim3(1), dim3(256), 0, s, BceArgs{logits, B, n0, y0, y1, probs, dlogit, metrics, is_g_step, gscale});
 }
 
 // d(logit) of sigmoid + BCE(mean) for row n, k_bce's own expression (so both kernels agree bit for bit)
@@ -1132,10 +1136,17 @@ __device__ __forceinline__ float bce_dlogit(float x, float y, float inv_count) {
 }
 // d(classifier input) * leaky'(a) * dropout.  Takes the logits, not d(logit): the backward chain then does not
 // wait for k_bce (metrics + d(logit) for the classifier's weight gradient), which runs beside it.
+// bce.logits != nullptr: one more block (the last) does k_bce's work -- the G step has the loss kernel and this one back to
+// back on its only lane, and neither needs the other
 template <class T>
-__global__ void k_cls_bwd(const float* __restrict__ logits, int B, int n0, float y0, float y1, const float* __restrict__ wcp,
+__global__ __launch_bounds__(256) void k_cls_bwd(const float* __restrict__ logits, int B, int n0, float y0, float y1, const float* __restrict__ wcp,
                           const T* __restrict__ act, const float* __restrict__ noise, float slope, T* __restrict__ dv,
-                          int64_t total, int C, float gscale) {
+                          int64_t total, int C, float gscale, const BceArgs bce) {
+    if (bce.logits != nullptr && blockIdx.x == gridDim.x - 1) {
+        __shared__ float sh[4];
+        bce_block(bce.logits, bce.B, bce.n0, bce.y0, bce.y1, bce.probs, bce.dlogit, bce.metrics, bce.is_g, bce.gscale, sh);
+        return;
+    }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int F = 16 * C;
@@ -1148,10 +1159,13 @@ __global__ void k_cls_bwd(const float* __restrict__ logits, int B, int n0, float
     st1<T>(dv + i, g);
 }
 void launch_cls_bwd(int dt, const float* logits, int n0, float y0, float y1, const float* wcp, const void* act, const float* noise,
-                    float slope, void* dv, int B, int C, hipStream_t s, float gscale) {
+                    float slope, void* dv, int B, int C, hipStream_t s, float gscale, float* bce_probs, float* bce_dlogit,
+                    float* bce_metrics, int bce_is_g, bool with_bce) {
     const int64_t total = (int64_t)B * 16 * C;
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_cls_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, logits, B, n0, y0, y1, wcp,
-                                                (const T*)act, noise, slope, (T*)dv, total, C, gscale));
+    BceArgs b = BceArgs{nullptr, 0, 0, 0.f, 0.f, nullptr, nullptr, nullptr, 0, 1.0f};
+    if (with_bce) b = BceArgs{logits, B, n0, y0, y1, bce_probs, bce_dlogit, bce_metrics, bce_is_g, gscale};
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_cls_bwd<T>, dim3(cdiv(total, 256) + (with_bce ? 1 : 0)), dim3(256), 0, s, logits, B, n0, y0,
+                                                y1, wcp, (const T*)act, noise, slope, (T*)dv, total, C, gscale, b));
 }
 // dWc[f] = sum_n dlogit[n] * act[n][f'], dbc = sum_n dlogit[n]: 64 features x 4 row lanes per block (rows n = lane, lane + 4,
 // ...), the four partial sums are added in lane order through LDS

@@ -724,10 +724,13 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
     // join.  D step: the weight gradients (lane a: they overlap the input-gradient chain, putting them on the main lane costs
     // 3 %) and the small reductions (lane b).  G step: nothing here is worth a lane -- the 5 us loss kernel stays on m.
     hipStream_t const sb = want_wgrad ? L.b : L.m;
-    if (sb != L.m) L.fork(L.b);
-    launch_bce(c->logits + r0, Bd, bce.n0, bce.y0, bce.y1, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, sb, c->gscale);
+    if (sb != L.m) {
+        L.fork(L.b);
+        launch_bce(c->logits + r0, Bd, bce.n0, bce.y0, bce.y1, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, sb, c->gscale);
+    }
+    // (G step: the loss kernel's work is one more block of the classifier's input-gradient kernel -- one launch, not two)
     launch_cls_bwd(c->dt, c->logits + r0, bce.n0, bce.y0, bce.y1, c->wcp, act(Ld), nz(Ld), slope, dvp(Ld), Bd,
-                   c->dC[Ld], L.m, c->gscale);
+                   c->dC[Ld], L.m, c->gscale, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, sb == L.m);
     if (want_wgrad)
         launch_cls_wgrad(c->dt, c->dlogit + r0, act(Ld), G_(di_cls_w(c)), G_(di_cls_b(c)), Bd, c->dC[Ld], sb);
     for (int l = Ld; l >= 2; --l) {
