@@ -41,6 +41,11 @@ struct GConvArgs {
     const float* bnp;     // EPI_BN_BWD_STATS: [scale | shift | mean | rstd] of the output's BatchNorm, Co floats each
     float* stat0;         // EPI_BN_BWD_STATS: partial rows [nrows][Co] of sum(dr); launch_gconv returns nrows and puts the
     float* stat1;         //   rows of sum(dr * xhat) right behind them (stat1 = stat0 + nrows * Co, filled by launch_gconv)
+    const float* cls_w;   // optional (last Discriminator block): the classifier's weight in the output's own (NHWC) order, Ho*Wo*Co
+    float* cls_part;      //   floats.  When the launch ends in k_splitk_epilogue, each of its workgroups also writes the partial
+                          //   dot product of its 1024 stored output values with cls_w to cls_part[workgroup] (P = Ho*Wo*Co / 1024
+                          //   consecutive partials per image); launch_gconv returns P, or 0 when the epilogue ran elsewhere (the
+                          //   caller then runs k_cls_fwd)
     float slope;
     // split-K scratch (optional): nsplit fp32 slabs of the whole output, summed by k_splitk_epilogue
     float* slab;

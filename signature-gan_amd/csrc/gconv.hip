@@ -569,6 +569,19 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int 
         }
     }
     st4<T>(static_cast<T*>(a.out) + i * 4, f32x4{v.x, v.y, v.z, v.w});
+    if (a.cls_w) {
+        // the classifier's dot product over the values just stored (as stored: rounded to T), 1024 of them per workgroup; every
+        // thread is here (launch_gconv: total4 % 256 == 0, per_img % 256 == 0)
+        __shared__ float shc[4];
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.cls_w + (size_t)(p2 ? (i & (per_img - 1)) : (i % per_img)) * 4);
+        float d = (float)(T)v.x * w4[0];
+        d = fmaf((float)(T)v.y, w4[1], d); d = fmaf((float)(T)v.z, w4[2], d); d = fmaf((float)(T)v.w, w4[3], d);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+        if ((threadIdx.x & 63) == 0) shc[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) a.cls_part[blockIdx.x] = ((shc[0] + shc[1]) + shc[2]) + shc[3];
+    }
 }
 
 Prof* g_prof = nullptr;
@@ -625,6 +638,11 @@ static int launch_cfg(const GConvArgs& a_in, hipStream_t st, int id, int nsplit)
         if (nsplit > 1 && (256 % (a.Co / 4)) != 0) nsplit = 1;
         rows = nsplit > 1 ? (int)((total4 + 255) / 256) : ((a.M + BM - 1) / BM) * ncls;
         a.stat1 = a.stat0 + (size_t)rows * a.Co;
+    }
+    if (a.cls_w) {
+        const int64_t per_img4 = (int64_t)a.Ho * a.Wo * a.Co / 4;
+        if (nsplit > 1 && a.epi != EPI_BN_BWD_STATS && total4 % 256 == 0 && per_img4 % 256 == 0) rows = (int)(per_img4 / 256);
+        else a.cls_w = nullptr;
     }
     dim3 grid(tiles, nsplit, ncls);
     // algorithmic FLOPs = 2 * M * Co * (taps * Ci) per class (== 2 * conv MACs, padding taps included)

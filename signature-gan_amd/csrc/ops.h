@@ -118,12 +118,14 @@ void launch_cls_features(int dt, const void* act, float* feat, int B, int C, hip
 // gscale: d(logit) is multiplied by it (the fp16 gradient scale; every gradient downstream then carries it and the optimiser
 // step divides it out again -- 1 for fp32 / bf16)
 void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* probs, float* dlogit,
-                float* metrics, int is_g_step, hipStream_t s, float gscale = 1.0f);
+                float* metrics, int is_g_step, hipStream_t s, float gscale = 1.0f, const float* parts = nullptr, int P = 0,
+                const float* bc = nullptr);
 // dv[n][hw][c] = dlogit[n] * wcp[hw*C+c] * leaky'(act) * noise[n][c]
 // from the logits (rows < n0: target y0, the rest y1; each segment's mean): d(logit) is recomputed with k_bce's expression
 void launch_cls_bwd(int dt, const float* logits, int n0, float y0, float y1, const float* wcp, const void* act, const float* noise,
                     float slope, void* dv, int B, int C, hipStream_t s, float gscale = 1.0f, float* bce_probs = nullptr,
-                    float* bce_dlogit = nullptr, float* bce_metrics = nullptr, int bce_is_g = 0, bool with_bce = false);
+                    float* bce_dlogit = nullptr, float* bce_metrics = nullptr, int bce_is_g = 0, bool with_bce = false,
+                    const float* parts = nullptr, int P = 0, const float* bc = nullptr);
 // dWc (torch order c*16+hw) and dbc
 void launch_cls_wgrad(int dt, const float* dlogit, const void* act, float* dWc, float* dbc, int B, int C, hipStream_t s);
 // dst[i] = (float)src[i] for a tensor of element type dt

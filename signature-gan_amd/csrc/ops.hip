@@ -1089,14 +1089,28 @@ void launch_cls_features(int dt, const void* act, float* feat, int B, int C, hip
 __device__ __forceinline__ float bce_dlogit(float x, float y, float inv_count);
 // nn.Sigmoid + nn.BCELoss(mean) per segment and its gradient w.r.t. the logit (torch formulas:
 // log clamped at -100; grad_p = (p - y) / max((1 - p) * p, 1e-12) / count; dlogit = grad_p * p * (1 - p))
-struct BceArgs { const float* logits; int B, n0; float y0, y1; float* probs; float* dlogit; float* metrics; int is_g; float gscale; };
-__device__ __forceinline__ void bce_block(const float* __restrict__ logits, int B, int n0, float y0, float y1,
+// The logit of row n: stored (k_cls_fwd), or -- when the last block's split-K epilogue left P partial dot products per image
+// (GConvArgs::cls_part) -- their sum in order plus the bias.  k_bce and k_cls_bwd use this one expression: they agree bit for bit.
+struct LogitSrc { const float* logits; const float* parts; int P; const float* bc; };
+__device__ __forceinline__ float logit_of(const LogitSrc& q, int64_t n) {
+    if (q.P == 0) return q.logits[n];
+    float v[16];                                  // P <= 16: every load in flight before the first add (a run-time loop
+#pragma unroll                                    // compiles to load, wait, add per partial: 8 dependent round trips)
+    for (int p = 0; p < 16; ++p) v[p] = q.parts[n * q.P + (p < q.P ? p : 0)];
+    float s = v[0];
+#pragma unroll
+    for (int p = 1; p < 16; ++p) s += p < q.P ? v[p] : 0.f;
+    return s + q.bc[0];
+}
+struct BceArgs { LogitSrc src; float* logits_out; int B, n0; float y0, y1; float* probs; float* dlogit; float* metrics; int is_g; float gscale; };
+__device__ __forceinline__ void bce_block(const LogitSrc src, float* __restrict__ logits_out, int B, int n0, float y0, float y1,
                                           float* __restrict__ probs, float* __restrict__ dlogit,
                                           float* __restrict__ metrics, int is_g, float gscale, float* sh) {
     float l0 = 0.f, l1 = 0.f, p0 = 0.f, p1 = 0.f, a0 = 0.f, a1 = 0.f;
     const float c0 = 1.0f / (float)(n0 > 0 ? n0 : 1), c1 = 1.0f / (float)(B - n0 > 0 ? B - n0 : 1);
     for (int n = threadIdx.x; n < B; n += 256) {
-        const float x = logits[n];
+        const float x = logit_of(src, n);
+        if (src.P && logits_out) logits_out[n] = x;
         const float p = 1.0f / (1.0f + expf(-x));
         const bool s0 = n < n0;
         const float y = s0 ? y0 : y1;
@@ -1121,11 +1135,12 @@ __device__ __forceinline__ void bce_block(const float* __restrict__ logits, int 
 }
 __global__ __launch_bounds__(256) void k_bce(const BceArgs b) {
     __shared__ float sh[4];
-    bce_block(b.logits, b.B, b.n0, b.y0, b.y1, b.probs, b.dlogit, b.metrics, b.is_g, b.gscale, sh);
+    bce_block(b.src, b.logits_out, b.B, b.n0, b.y0, b.y1, b.probs, b.dlogit, b.metrics, b.is_g, b.gscale, sh);
 }
 void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* probs, float* dlogit, float* metrics,
-                int is_g_step, hipStream_t s, float gscale) {
-    hipLaunchKernelGGL(k_bce, dim3(1), dim3(256), 0, s, BceArgs{logits, B, n0, y0, y1, probs, dlogit, metrics, is_g_step, gscale});
+                int is_g_step, hipStream_t s, float gscale, const float* parts, int P, const float* bc) {
+    hipLaunchKernelGGL(k_bce, dim3(1), dim3(256), 0, s,
+                       BceArgs{LogitSrc{logits, parts, P, bc}, const_cast<float*>(logits), B, n0, y0, y1, probs, dlogit, metrics, is_g_step, gscale});
 }
 
 // d(logit) of sigmoid + BCE(mean) for row n, k_bce's own expression (so both kernels agree bit for bit)
@@ -1141,31 +1156,33 @@ __device__ __forceinline__ float bce_dlogit(float x, float y, float inv_count) {
 template <class T>
 __global__ __launch_bounds__(256) void k_cls_bwd(const float* __restrict__ logits, int B, int n0, float y0, float y1, const float* __restrict__ wcp,
                           const T* __restrict__ act, const float* __restrict__ noise, float slope, T* __restrict__ dv,
-                          int64_t total, int C, float gscale, const BceArgs bce) {
-    if (bce.logits != nullptr && blockIdx.x == gridDim.x - 1) {
-        __shared__ float sh[4];
-        bce_block(bce.logits, bce.B, bce.n0, bce.y0, bce.y1, bce.probs, bce.dlogit, bce.metrics, bce.is_g, bce.gscale, sh);
+                          int64_t total, int C, float gscale, const BceArgs bce, int with_bce) {
+    __shared__ float sh[4];
+    if (with_bce && blockIdx.x == gridDim.x - 1) {
+        bce_block(bce.src, bce.logits_out, bce.B, bce.n0, bce.y0, bce.y1, bce.probs, bce.dlogit, bce.metrics, bce.is_g, bce.gscale, sh);
         return;
     }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
     const int F = 16 * C;
+    if (i >= total) return;
+    const float x = logit_of(bce.src, i / F);     // (every lane for itself: the partials are L1 hits beside the act / weight loads;
+                                                  //  one lane + LDS broadcast + barrier doubled the kernel's time)
     const int j = (int)(i % F), c = j % C;
     const int64_t n = i / F;
     const bool s0 = n < n0;
-    const float dl = bce_dlogit(logits[n], s0 ? y0 : y1, 1.0f / (float)(s0 ? (n0 > 0 ? n0 : 1) : (B - n0 > 0 ? B - n0 : 1))) * gscale;
+    const float dl = bce_dlogit(x, s0 ? y0 : y1, 1.0f / (float)(s0 ? (n0 > 0 ? n0 : 1) : (B - n0 > 0 ? B - n0 : 1))) * gscale;
     float g = dl * wcp[j] * (ld1<T>(act + i) > 0.f ? 1.f : slope);
     if (noise) g *= noise[n * C + c];
     st1<T>(dv + i, g);
 }
 void launch_cls_bwd(int dt, const float* logits, int n0, float y0, float y1, const float* wcp, const void* act, const float* noise,
                     float slope, void* dv, int B, int C, hipStream_t s, float gscale, float* bce_probs, float* bce_dlogit,
-                    float* bce_metrics, int bce_is_g, bool with_bce) {
+                    float* bce_metrics, int bce_is_g, bool with_bce, const float* parts, int P, const float* bc) {
     const int64_t total = (int64_t)B * 16 * C;
-    BceArgs b = BceArgs{nullptr, 0, 0, 0.f, 0.f, nullptr, nullptr, nullptr, 0, 1.0f};
-    if (with_bce) b = BceArgs{logits, B, n0, y0, y1, bce_probs, bce_dlogit, bce_metrics, bce_is_g, gscale};
+    const BceArgs b = BceArgs{LogitSrc{logits, parts, P, bc}, const_cast<float*>(logits), B, n0, y0, y1, bce_probs, bce_dlogit, bce_metrics,
+                              bce_is_g, gscale};
     SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_cls_bwd<T>, dim3(cdiv(total, 256) + (with_bce ? 1 : 0)), dim3(256), 0, s, logits, B, n0, y0,
-                                                y1, wcp, (const T*)act, noise, slope, (T*)dv, total, C, gscale, b));
+                                                y1, wcp, (const T*)act, noise, slope, (T*)dv, total, C, gscale, b, with_bce ? 1 : 0));
 }
 // dWc[f] = sum_n dlogit[n] * act[n][f'], dbc = sum_n dlogit[n]: 64 features x 4 row lanes per block (rows n = lane, lane + 4,
 // ...), the four partial sums are added in lane order through LDS

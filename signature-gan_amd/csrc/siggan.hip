@@ -154,6 +154,8 @@ struct siggan_ctx {
     char *d_a[MAXL + 1], *d_dv[MAXL + 1];
     float *d_noise[MAXL + 1];
     float *logits, *probs, *dlogit;
+    float* lparts;       // partial classifier dot products left by the last block's split-K epilogue: lP[h] per image of workspace half h
+    int lP[2];           //   (0: that half's logits are in `logits`, written by k_cls_fwd)
     char *g_up[MAXL + 1], *g_dn[MAXL + 1], *d_dn[MAXL + 1], *d_up[MAXL + 1];
     float *wcp;
     float *slab, *slab_k, *slab_k2, *slab_k3, *partial, *partial_b, *partial_c, *z_g, *img_g, *metrics, *zeros, *wfc_t, *wfin_t, *d_w1t, *real_stage, *mask_stage;
@@ -312,6 +314,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
             carve(&c->d_noise[l], Bd * c->dC[l]);
         }
         carve(&c->logits, Bd); carve(&c->probs, Bd); carve(&c->dlogit, Bd);
+        carve(&c->lparts, (int64_t)Bd * 16);
         for (int l = 1; l <= c->Lg; ++l) {
             carve_t(&c->g_up[l], (int64_t)c->gC[l - 1] * c->gC[l] * 16);
             carve_t(&c->g_dn[l], (int64_t)c->gC[l - 1] * c->gC[l] * 16);
@@ -681,7 +684,8 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
 // Discriminator conv blocks + classifier logits for nB images written to workspace rows
 // [r0, r0 + nB) (the D step runs D(real) into rows [0,B) on a side lane while the Generator
 // produces the fakes, then D(fake) into rows [B,2B); backward treats the 2B rows as one batch).
-static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool dropout, hipStream_t s, float* slab_k) {
+static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool dropout, hipStream_t s, float* slab_k,
+                           bool fuse_cls = false) {
     const float slope = c->cfg.leaky_slope;
     auto act = [&](int l) { const int64_t H = c->S >> l; return c->d_a[l] + (size_t)((int64_t)r0 * H * H * c->dC[l]) * c->es; };
     auto nz = [&](int l) { return dropout ? c->d_noise[l] + (int64_t)r0 * c->dC[l] : nullptr; };
@@ -694,9 +698,15 @@ static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool d
         a.B = nB; a.Hi = Hi; a.Wi = Hi; a.Ci = c->dC[l - 1]; a.Co = c->dC[l];
         a.lgHr = ilog2i(Ho); a.lgWr = a.lgHr; a.Ho = Ho; a.Wo = Ho; a.form = 0; a.M = nB * Ho * Ho;
         a.epi = EPI_BIAS_LRELU_DROP; a.bias = DP(c, di_b(l)); a.noise = nz(l); a.slope = slope;
-        launch_gconv(a, s);
+        // fuse_cls (the step phases, whose k_bce / k_cls_bwd read either form): when the last block ends in a split-K epilogue,
+        // the classifier's dot product rides there as P partials per image and k_cls_fwd is not launched
+        const int P_max = c->dC[c->Ld] * 16 / 1024;
+        if (l == c->Ld && fuse_cls && P_max >= 1 && P_max <= 16) { a.cls_w = c->wcp; a.cls_part = c->lparts + (size_t)r0 * P_max; }
+        const int P = launch_gconv(a, s);
+        if (l == c->Ld) c->lP[r0 == 0 ? 0 : 1] = a.cls_w ? P : 0;
     }
-    launch_cls_fwd(c->dt, act(c->Ld), c->wcp, DP(c, di_cls_b(c)), c->logits + r0, nB, c->dC[c->Ld] * 16, s);
+    if (c->lP[r0 == 0 ? 0 : 1] == 0)
+        launch_cls_fwd(c->dt, act(c->Ld), c->wcp, DP(c, di_cls_b(c)), c->logits + r0, nB, c->dC[c->Ld] * 16, s);
 }
 
 // Backward through the Discriminator from d(logit).  want_wgrad: fill the D gradient arena
@@ -724,13 +734,20 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
     // join.  D step: the weight gradients (lane a: they overlap the input-gradient chain, putting them on the main lane costs
     // 3 %) and the small reductions (lane b).  G step: nothing here is worth a lane -- the 5 us loss kernel stays on m.
     hipStream_t const sb = want_wgrad ? L.b : L.m;
+    // the logits of the rows this pass covers: stored, or P partial dot products per image (d_forward_rows).  Both halves of a
+    // 2B-row pass were produced with the same batch size, hence in the same form
+    const int hP = c->lP[r0 == 0 ? 0 : 1];
+    const int P = (r0 == 0 && Bd > bce.n0 && bce.n0 > 0 && c->lP[1] != hP) ? -1 : hP;
+    if (P < 0) { c->lane_err = hipErrorInvalidValue; return; }       // (cannot happen: reported, not computed wrongly)
+    const float* const parts = P ? c->lparts + (size_t)r0 * P : nullptr;
+    const float* const bc = DP(c, di_cls_b(c));
     if (sb != L.m) {
         L.fork(L.b);
-        launch_bce(c->logits + r0, Bd, bce.n0, bce.y0, bce.y1, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, sb, c->gscale);
+        launch_bce(c->logits + r0, Bd, bce.n0, bce.y0, bce.y1, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, sb, c->gscale, parts, P, bc);
     }
     // (G step: the loss kernel's work is one more block of the classifier's input-gradient kernel -- one launch, not two)
     launch_cls_bwd(c->dt, c->logits + r0, bce.n0, bce.y0, bce.y1, c->wcp, act(Ld), nz(Ld), slope, dvp(Ld), Bd,
-                   c->dC[Ld], L.m, c->gscale, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, sb == L.m);
+                   c->dC[Ld], L.m, c->gscale, c->probs + r0, c->dlogit + r0, bce.mt, bce.is_g, sb == L.m, parts, P, bc);
     if (want_wgrad)
         launch_cls_wgrad(c->dt, c->dlogit + r0, act(Ld), G_(di_cls_w(c)), G_(di_cls_b(c)), Bd, c->dC[Ld], sb);
     for (int l = Ld; l >= 2; --l) {
@@ -922,7 +939,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         make_noise(c, k.has_masks ? c->mask_stage : nullptr, B, k.pre_real == 2 ? 1 : 0, 2, L.a);
     // D(real) beside the Generator (train...py:309) -- unless the previous siggan_g_grads already ran it
     // (siggan_stage_real) beside its Generator backward; then bce only has to wait for that lane
-    if (k.pre_real != 2) d_forward_rows(c, c->real_stage, 0, B, drop, L.a, c->slab_k2);
+    if (k.pre_real != 2) d_forward_rows(c, c->real_stage, 0, B, drop, L.a, c->slab_k2, true);
     }
     const float* fake = c->img;
     const bool spec_fwd = k.spec_g && k.variant != SIGGAN_STEP_ABLATION;
@@ -956,7 +973,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // scratch).  It forks HERE but is enqueued after D(fake), whose kernels the dispatcher should see first.
     hipEvent_t e_spec = nullptr;
     if (spec_fwd && !spec_early) { e_spec = L.next(); L.record(e_spec, L.m); }
-    d_forward_rows(c, fake, B, B, drop, L.m, c->slab_k);             // D(fake) into rows [B, 2B)
+    d_forward_rows(c, fake, B, B, drop, L.m, c->slab_k, true);       // D(fake) into rows [B, 2B)
     if (k.pre_real == 2 && !c->dreal_joined) L.wait(L.m, c->ev_dreal);
     c->dreal_joined = c->dreal_noise2 = false;
     if (spec_fwd && !spec_early) {
@@ -1013,10 +1030,10 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         L.fork(c->s_c);                                               // D's packs are complete on m here
         if (drop) make_noise(c, nullptr, B, 0, 2, c->s_c, 1);       // the D(fake) pass' tables too (this G step's pass has no dropout)
         c->dreal_noise2 = drop;
-        d_forward_rows(c, c->staged_src, 0, B, drop, c->s_c, c->slab_k2);
+        d_forward_rows(c, c->staged_src, 0, B, drop, c->s_c, c->slab_k2, true);
         L.record(c->ev_dreal, c->s_c);
     }
-    d_forward_rows(c, img, r0g, B, gdrop, L.m, c->slab_k);
+    d_forward_rows(c, img, r0g, B, gdrop, L.m, c->slab_k, true);
     d_backward_pass(c, L, img, B, img, B, gdrop, false, true, BceSpec{B, gy, gy, k.mt, 1}, r0g);   // through D into the image; no D weight grads
     if (k.pre_real && !real_early) {
         // siggan_stage_real: the NEXT D step's D(real) forward needs the Discriminator as it is now (its
@@ -1026,7 +1043,7 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         const bool drop = c->cfg.dropout > 0.f;
         L.fork(c->s_c);
         if (drop) make_noise(c, nullptr, B, 0, 1, c->s_c, 1);
-        d_forward_rows(c, c->staged_src, 0, B, drop, c->s_c, c->slab_k2);
+        d_forward_rows(c, c->staged_src, 0, B, drop, c->s_c, c->slab_k2, true);
         L.record(c->ev_dreal, c->s_c);
     }
     g_backward_pass(c, L, zg, B);
