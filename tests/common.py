@@ -18,7 +18,8 @@ from oracle import siggan_oracle as O                # noqa: E402  (the checker)
 
 GOLDEN = os.path.join(HERE, "golden")
 CASES = [(64, 100, 4), (64, 100, 64), (128, 128, 4), (128, 128, 32), (64, 100, 128),   # (64, 100, 128): BASELINE configs[3]
-         (64, 100, 5)]      # an odd batch: ragged row tiles in every GEMM, five samples per BatchNorm statistic
+         (64, 100, 5),      # an odd batch: ragged row tiles in every GEMM, five samples per BatchNorm statistic
+         (128, 128, 5)]     # the same at 128x128 (five blocks per network, the 64-channel patch kernel)
 SEED = dict(state_g=101, state_d=202, adam_g=303, adam_d=404, z=11, real=22)
 
 
