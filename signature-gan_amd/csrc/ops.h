@@ -53,6 +53,9 @@ struct PrepTable {
 };
 void prep_add(PrepTable& t, const PrepJob& j, long long count);
 bool launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s);   // false: the table overflowed (nothing launched)
+// the same plus a first-Discriminator-block forward (no dropout table) of B images, as further blocks of the one launch
+bool launch_prepare_conv1(const PrepTable& t, float bn_eps, int dt, const float* x, const float* W, const float* b, float slope,
+                          void* out, int B, int S, hipStream_t s);
 
 // ---- Generator pieces ---------------------------------------------------------------------
 // y[n][f'] = z[n,:] . W[f,:] + b[f],  f' = hw*C0 + c  <->  f = c*16 + hw   (NHWC feature order)

@@ -92,12 +92,12 @@ __device__ __forceinline__ void put_w(const PrepJob& q, size_t idx, float v) {
     else if (q.dt == DT_BF16) reinterpret_cast<bf16_t*>(q.dst)[idx] = (bf16_t)v;
     else reinterpret_cast<f16_t*>(q.dst)[idx] = (f16_t)v;
 }
-__global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
+__device__ __forceinline__ void prepare_unit(const PrepTable& t, float eps, unsigned bid) {
     extern __shared__ float tile[];
     int j = 0;
-    while ((long long)blockIdx.x >= t.prefix[j + 1]) ++j;
+    while ((long long)bid >= t.prefix[j + 1]) ++j;
     const PrepJob& q = t.job[j];
-    const int u = (int)(blockIdx.x - t.prefix[j]);
+    const int u = (int)(bid - t.prefix[j]);
     const int tid = threadIdx.x;
     if (q.type == PREP_PACK_DOWN || q.type == PREP_CLS) {
         const int I = q.type == PREP_CLS ? q.O : q.I;
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) {
         }
     }
 }
+__global__ __launch_bounds__(256) void k_prepare(const PrepTable t, float eps) { prepare_unit(t, eps, blockIdx.x); }
 bool launch_prepare(const PrepTable& t, float bn_eps, hipStream_t s) {
     if (t.overflow) return false;
     if (t.njobs == 0) return true;
@@ -857,15 +858,15 @@ __device__ __forceinline__ void stage_x(float* sx, const float* xp, int oh0, int
 // a block produces RY output rows of one image from an LDS copy of the input rows (broadcast reads)
 // and writes 256 contiguous bytes per pixel.
 template <class T>
-__global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x0, int n0, const float* __restrict__ x1,
-                                                   const float* __restrict__ W, const float* __restrict__ b,
-                                                   const float* __restrict__ noise, float slope,
-                                                   T* __restrict__ out, int S) {
+__device__ __forceinline__ void conv1_fwd_block(const float* __restrict__ x0, int n0, const float* __restrict__ x1,
+                                                const float* __restrict__ W, const float* __restrict__ b,
+                                                const float* __restrict__ noise, float slope,
+                                                T* __restrict__ out, int S, unsigned bid) {
     constexpr int RY = 2, C = 64;
     __shared__ float sx[(2 * RY + 2) * 130];
     __shared__ __attribute__((aligned(16))) float sw[16 * (C + 4)];  // weights transposed to [tap][co] (row stride C + 4: conflict-free both ways)
     const int Ho = S >> 1, nby = Ho / RY, Wp = S + 2;
-    const int n = blockIdx.x / nby, oh0 = (blockIdx.x % nby) * RY;
+    const int n = bid / nby, oh0 = (bid % nby) * RY;
     const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
     stage_x<RY>(sx, seg_ptr(x0, n0, x1, n, S), oh0, S);
     for (int i = threadIdx.x; i < 16 * C; i += 256) sw[(i & 15) * (C + 4) + (i >> 4)] = W[i];
@@ -894,6 +895,31 @@ __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x0,
         if (noise) { acc.x *= nz.x; acc.y *= nz.y; acc.z *= nz.z; acc.w *= nz.w; }
         st4<T>(out + (((size_t)n * Ho + oh0 + r) * Ho + ow) * C + q * 4, acc);
     }
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x0, int n0, const float* __restrict__ x1,
+                                                   const float* __restrict__ W, const float* __restrict__ b,
+                                                   const float* __restrict__ noise, float slope,
+                                                   T* __restrict__ out, int S) {
+    conv1_fwd_block<T>(x0, n0, x1, W, b, noise, slope, out, S, blockIdx.x);
+}
+// The Discriminator's weight re-packs and a first-block forward that does not read them, in ONE launch: in the G step the two
+// stand back to back on the main lane (packs of the just-updated D, then D(fake) of the new images) and share nothing --
+// blocks [0, nprep) are k_prepare's units, the blocks behind them k_conv1_fwd's.
+template <class T>
+__global__ __launch_bounds__(256) void k_prepare_conv1(const PrepTable t, float eps, unsigned nprep, const float* __restrict__ x,
+                                                       int nB, const float* __restrict__ W, const float* __restrict__ b,
+                                                       float slope, T* __restrict__ out, int S) {
+    if (blockIdx.x < nprep) prepare_unit(t, eps, blockIdx.x);
+    else conv1_fwd_block<T>(x, nB, x, W, b, nullptr, slope, out, S, blockIdx.x - nprep);
+}
+bool launch_prepare_conv1(const PrepTable& t, float bn_eps, int dt, const float* x, const float* W, const float* b, float slope,
+                          void* out, int B, int S, hipStream_t s) {
+    if (t.overflow) return false;
+    const unsigned nprep = (unsigned)t.prefix[t.njobs];
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_prepare_conv1<T>, dim3(nprep + (unsigned)(B * (S / 4))), dim3(256), 512 * 17 * sizeof(float), s,
+                                                t, bn_eps, nprep, x, B, W, b, slope, (T*)out, S));
+    return true;
 }
 void launch_conv1_fwd(int dt, const float* x0, int n0, const float* x1, const float* W, const float* b, const float* noise,
                       float slope, void* out, int B, int S, int C, hipStream_t s) {

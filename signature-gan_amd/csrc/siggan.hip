@@ -527,7 +527,10 @@ static int check_call(siggan_ctx* c, int batch, bool need_bound = true) {
 
 // One launch per network rebuilds everything derived from its arena: GEMM-friendly weight copies and
 // (for G) the BatchNorm eval-mode scale/shift tables.  sg / sd: the lanes the two launches go to.
-static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, bool do_d, int sn_slot = 0) {
+// conv1_x != nullptr (G step, no spectral norm): the D table's launch also runs the first-block forward of conv1_B images at
+// conv1_x into workspace rows [conv1_r0, ...) -- it reads the raw block-1 weights, not a pack (launch_prepare_conv1)
+static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, bool do_d, int sn_slot = 0, const float* conv1_x = nullptr,
+                   int conv1_r0 = 0, int conv1_B = 0) {
     if (do_g) {
         PrepTable t; t.njobs = 0; t.overflow = 0;
         PrepJob j; memset(&j, 0, sizeof j);
@@ -585,7 +588,15 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
         j.type = PREP_TAPS; j.I = 16; j.O = c->dC[1]; j.src = DP(c, di_w(1)); j.dst = c->d_w1t;
         if (c->sn) j.mul = c->sn_sig + (sn_slot * 2 + 1) * SnTable::MAXS;
         prep_add(t, j, j.O * 16);
-        if (!launch_prepare(t, BN_EPS, sd)) c->lane_err = hipErrorInvalidValue;
+        bool ok;
+        if (conv1_x && !c->sn) {
+            const int64_t H = c->S >> 1;
+            char* out = c->d_a[1] + (size_t)((int64_t)conv1_r0 * H * H * c->dC[1]) * c->es;
+            ok = launch_prepare_conv1(t, BN_EPS, c->dt, conv1_x, DP(c, di_w(1)), DP(c, di_b(1)), c->cfg.leaky_slope, out, conv1_B, c->S, sd);
+        } else {
+            ok = launch_prepare(t, BN_EPS, sd);
+        }
+        if (!ok) c->lane_err = hipErrorInvalidValue;
     }
 }
 
@@ -685,11 +696,12 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
 // [r0, r0 + nB) (the D step runs D(real) into rows [0,B) on a side lane while the Generator
 // produces the fakes, then D(fake) into rows [B,2B); backward treats the 2B rows as one batch).
 static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool dropout, hipStream_t s, float* slab_k,
-                           bool fuse_cls = false) {
+                           bool fuse_cls = false, bool conv1_done = false) {
     const float slope = c->cfg.leaky_slope;
     auto act = [&](int l) { const int64_t H = c->S >> l; return c->d_a[l] + (size_t)((int64_t)r0 * H * H * c->dC[l]) * c->es; };
     auto nz = [&](int l) { return dropout ? c->d_noise[l] + (int64_t)r0 * c->dC[l] : nullptr; };
-    launch_conv1_fwd(c->dt, x, nB, x, c->sn ? c->d_w1s : DP(c, di_w(1)), DP(c, di_b(1)), nz(1), slope, act(1), nB, c->S, c->dC[1], s);
+    if (!conv1_done)          // (done: it rode in the launch that re-packed D's weights, see repack)
+        launch_conv1_fwd(c->dt, x, nB, x, c->sn ? c->d_w1s : DP(c, di_w(1)), DP(c, di_b(1)), nz(1), slope, act(1), nB, c->S, c->dC[1], s);
     for (int l = 2; l <= c->Ld; ++l) {
         const int Hi = c->S >> (l - 1), Ho = Hi / 2;
         GConvArgs a = gconv_args(c);
@@ -992,10 +1004,14 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     const int B = k.B;
     const float* zg; float* img;
     const bool d_pack = !c->sn && k.d_dirty != 0;                    // (spectral norm: the packs follow sigma, below)
+    bool conv1_done = false;
     if (k.spec_g) {                                                  // forward already enqueued by siggan_step_begin
-        repack(c, L.m, L.m, false, d_pack);
         if (!c->gfwd_joined) L.wait(L.m, c->ev_gfwd);
         c->gfwd_joined = false;
+        // trainer step: the first-block forward of the new images (rows [B, 2B), no dropout in this pass) rides in the launch
+        // that re-packs D's weights -- it reads the raw block-1 weights, and the two would stand back to back on this lane
+        conv1_done = d_pack && k.variant != SIGGAN_STEP_ABLATION;
+        repack(c, L.m, L.m, false, d_pack, 0, conv1_done ? c->img_g : nullptr, B, B);
         zg = c->z_g; img = c->img_g;
     } else {
         L.fork(L.a);
@@ -1033,7 +1049,7 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         d_forward_rows(c, c->staged_src, 0, B, drop, c->s_c, c->slab_k2, true);
         L.record(c->ev_dreal, c->s_c);
     }
-    d_forward_rows(c, img, r0g, B, gdrop, L.m, c->slab_k, true);
+    d_forward_rows(c, img, r0g, B, gdrop, L.m, c->slab_k, true, conv1_done);
     d_backward_pass(c, L, img, B, img, B, gdrop, false, true, BceSpec{B, gy, gy, k.mt, 1}, r0g);   // through D into the image; no D weight grads
     if (k.pre_real && !real_early) {
         // siggan_stage_real: the NEXT D step's D(real) forward needs the Discriminator as it is now (its
