@@ -1188,7 +1188,8 @@ __global__ __launch_bounds__(256) void k_cls_bwd(const float* __restrict__ logit
         bce_block(bce.src, bce.logits_out, bce.B, bce.n0, bce.y0, bce.y1, bce.probs, bce.dlogit, bce.metrics, bce.is_g, bce.gscale, sh);
         return;
     }
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four consecutive channels per lane (C % 4 == 0: one image, one pixel): 16-byte loads and one store of four
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int F = 16 * C;
     if (i >= total) return;
     const float x = logit_of(bce.src, i / F);     // (every lane for itself: the partials are L1 hits beside the act / weight loads;
@@ -1197,9 +1198,16 @@ __global__ __launch_bounds__(256) void k_cls_bwd(const float* __restrict__ logit
     const int64_t n = i / F;
     const bool s0 = n < n0;
     const float dl = bce_dlogit(x, s0 ? y0 : y1, 1.0f / (float)(s0 ? (n0 > 0 ? n0 : 1) : (B - n0 > 0 ? B - n0 : 1))) * gscale;
-    float g = dl * wcp[j] * (ld1<T>(act + i) > 0.f ? 1.f : slope);
-    if (noise) g *= noise[n * C + c];
-    st1<T>(dv + i, g);
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wcp + j), a4 = ld4<T>(act + i);
+    f32x4 g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = dl * w4[e] * (a4[e] > 0.f ? 1.f : slope);
+    if (noise) {
+        const f32x4 nz = *reinterpret_cast<const f32x4*>(noise + n * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] *= nz[e];
+    }
+    st4<T>(dv + i, g);
 }
 void launch_cls_bwd(int dt, const float* logits, int n0, float y0, float y1, const float* wcp, const void* act, const float* noise,
                     float slope, void* dv, int B, int C, hipStream_t s, float gscale, float* bce_probs, float* bce_dlogit,
@@ -1207,7 +1215,7 @@ void launch_cls_bwd(int dt, const float* logits, int n0, float y0, float y1, con
     const int64_t total = (int64_t)B * 16 * C;
     const BceArgs b = BceArgs{LogitSrc{logits, parts, P, bc}, const_cast<float*>(logits), B, n0, y0, y1, bce_probs, bce_dlogit, bce_metrics,
                               bce_is_g, gscale};
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_cls_bwd<T>, dim3(cdiv(total, 256) + (with_bce ? 1 : 0)), dim3(256), 0, s, logits, B, n0, y0,
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_cls_bwd<T>, dim3(cdiv(total, 1024) + (with_bce ? 1 : 0)), dim3(256), 0, s, logits, B, n0, y0,
                                                 y1, wcp, (const T*)act, noise, slope, (T*)dv, total, C, gscale, b, with_bce ? 1 : 0));
 }
 // dWc[f] = sum_n dlogit[n] * act[n][f'], dbc = sum_n dlogit[n]: 64 features x 4 row lanes per block (rows n = lane, lane + 4,
