@@ -1147,8 +1147,22 @@ __device__ __forceinline__ void bce_block(const LogitSrc src, float* __restrict_
         if (s0) { l0 += loss; p0 += p; a0 += p > 0.5f ? 1.f : 0.f; }
         else    { l1 += loss; p1 += p; a1 += p < 0.5f ? 1.f : 0.f; }
     }
-    l0 = block_sum(l0, sh); l1 = block_sum(l1, sh); p0 = block_sum(p0, sh);
-    p1 = block_sum(p1, sh); a0 = block_sum(a0, sh); a1 = block_sum(a1, sh);
+    // the six sums in one pass (block_sum's order per value: wave tree, then the waves in order; one barrier pair, not six)
+    float v6[6] = {l0, l1, p0, p1, a0, a1};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+        for (int o = 32; o > 0; o >>= 1) v6[q] += __shfl_down(v6[q], o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sh[q * 4 + (threadIdx.x >> 6)] = v6[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { float t = 0.f; for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sh[q * 4 + k]; v6[q] = t; }
+        l0 = v6[0]; l1 = v6[1]; p0 = v6[2]; p1 = v6[3]; a0 = v6[4]; a1 = v6[5];
+    }
     if (threadIdx.x == 0 && metrics) {
         if (is_g) {
             metrics[8] = l0 * c0;        // g_loss
@@ -1160,7 +1174,7 @@ __device__ __forceinline__ void bce_block(const LogitSrc src, float* __restrict_
     }
 }
 __global__ __launch_bounds__(256) void k_bce(const BceArgs b) {
-    __shared__ float sh[4];
+    __shared__ float sh[24];
     bce_block(b.src, b.logits_out, b.B, b.n0, b.y0, b.y1, b.probs, b.dlogit, b.metrics, b.is_g, b.gscale, sh);
 }
 void launch_bce(const float* logits, int B, int n0, float y0, float y1, float* probs, float* dlogit, float* metrics,
@@ -1183,7 +1197,7 @@ template <class T>
 __global__ __launch_bounds__(256) void k_cls_bwd(const float* __restrict__ logits, int B, int n0, float y0, float y1, const float* __restrict__ wcp,
                           const T* __restrict__ act, const float* __restrict__ noise, float slope, T* __restrict__ dv,
                           int64_t total, int C, float gscale, const BceArgs bce, int with_bce) {
-    __shared__ float sh[4];
+    __shared__ float sh[24];
     if (with_bce && blockIdx.x == gridDim.x - 1) {
         bce_block(bce.src, bce.logits_out, bce.B, bce.n0, bce.y0, bce.y1, bce.probs, bce.dlogit, bce.metrics, bce.is_g, bce.gscale, sh);
         return;
