@@ -253,11 +253,12 @@ def d_forward(sd, x, size, masks=None, dropout=0.25, slope=0.2, signs=None, reco
 
 
 def bce(p: Tensor, y: float) -> Tensor:
-    """nn.BCELoss(reduction='mean') on probabilities (vanilla_gan_model.py:107): log terms
-    clamped at -100 (torch semantics)."""
-    t = torch.full_like(p, y)
-    return -(t * torch.clamp(torch.log(p), min=-100.0)
-             + (1.0 - t) * torch.clamp(torch.log(1.0 - p), min=-100.0)).mean()
+    """nn.BCELoss(reduction='mean') on probabilities (vanilla_gan_model.py:107) -- the very torch operator the reference's
+    criterion calls: log terms clamped at -100 in the forward pass, and a backward pass of its own,
+    (p - y) / max((1 - p) * p, 1e-12) / count, which stays finite when a prediction saturates to exactly 0 or 1 (differentiating
+    the clamped logarithms by autograd gives 0 * inf = NaN there: the third step of the 128x128 batch-4 sequence fixture,
+    d_real_mean 0.9999993, is such a case)."""
+    return F.binary_cross_entropy(p, torch.full_like(p, y))
 
 
 # --------------------------------------------------------------------------------------

@@ -148,6 +148,8 @@ struct siggan_ctx {
     char* ws; size_t ws_bytes;
     // (element type dt: fc_y, g_y, g_a, g_da, d_a, d_dv and the MFMA weight packs g_up, g_dn, d_dn, d_up; fp32: the rest)
     float *z, *g_bn[MAXL + 1], *g_bne[MAXL + 1];
+    XAcc *xacc_f[MAXL + 1], *xacc_b[MAXL + 1];   // exact accumulators of the Generator blocks' BatchNorm statistics: forward [2][C], backward [2][C] (xacc.h)
+    unsigned* tickets;                           // their arrival counters: [l] forward, [MAXL + 1 + l] backward; zero between uses
     char *fc_y, *g_y[MAXL + 1], *g_a[MAXL + 1], *g_da[MAXL + 1];
     char *g_ae[MAXL + 1];     // 16-bit contexts: activations of the EVAL-mode Generator forward (it runs beside the training forward)
     float *img, *dpre;
@@ -303,7 +305,14 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
             carve_t(&c->g_da[l], n);
             carve(&c->g_bn[l], 6 * (int64_t)(l == 0 ? c->F : c->gC[l]));
             carve(&c->g_bne[l], 4 * (int64_t)(l == 0 ? c->F : c->gC[l]));   // eval-mode [scale|shift|mean|rstd]
+            if (l >= 1) {
+                float *xf = nullptr, *xb = nullptr;
+                carve(&xf, 2 * (int64_t)c->gC[l] * (int64_t)(sizeof(XAcc) / sizeof(float)));
+                carve(&xb, 2 * (int64_t)c->gC[l] * (int64_t)(sizeof(XAcc) / sizeof(float)));
+                if (pass == 1) { c->xacc_f[l] = (XAcc*)xf; c->xacc_b[l] = (XAcc*)xb; }
+            }
         }
+        { float* tk = nullptr; carve(&tk, 64); if (pass == 1) c->tickets = (unsigned*)tk; }
         if (pass == 1) c->g_y[0] = c->fc_y;
         carve(&c->img, Bm * c->S * c->S);
         carve(&c->dpre, Bm * c->S * c->S);
@@ -478,6 +487,7 @@ extern "C" int siggan_bind(siggan_ctx* c, const siggan_storage* st) {
     }
     c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0; c->staged_B = 0;
     c->adam_t_known[0] = c->adam_t_known[1] = false;
+    c->early_ar = false;               // (an early all-reduce whose apply never ran is abandoned with the gradients it covered)
     drop_dreal(c);
     return SIGGAN_OK;
 }
@@ -485,6 +495,7 @@ extern "C" int siggan_params_changed(siggan_ctx* c) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     c->g_dirty = c->d_dirty = true;
     c->adam_t_known[0] = c->adam_t_known[1] = false;      // (optimizer.load_state_dict writes the step tensors)
+    c->early_ar = false;
     drop_dreal(c);                     // a D(real) forward started ahead of time used the old weights
     return SIGGAN_OK;
 }
@@ -641,6 +652,19 @@ static GConvArgs gconv_args(siggan_ctx* c) {
     return a;
 }
 
+// What the last workgroup of a statistics epilogue finalizes for Generator block l (xacc.h): kind 1 = the batch statistics of
+// its pre-BatchNorm tensor y[l] (table + running statistics), kind 2 = the BatchNorm-backward sums of d(relu output) of block l.
+static BnFin bn_fin(siggan_ctx* c, int l, int kind, int64_t R) {
+    BnFin f; memset(&f, 0, sizeof f);
+    f.kind = kind; f.acc = kind == 1 ? c->xacc_f[l] : c->xacc_b[l]; f.ticket = c->tickets + (kind == 1 ? l : MAXL + 1 + l);
+    f.bn = c->g_bn[l]; f.R = R; f.momentum = BN_MOMENTUM; f.eps = BN_EPS;
+    f.gamma = GP(c, gi_bn_w(l)); f.beta = GP(c, gi_bn_b(l));
+    f.rmean = c->st.g_bn_running_mean + c->g_bn_off[l]; f.rvar = c->st.g_bn_running_var + c->g_bn_off[l];
+    f.batches = c->st.g_bn_batches + l;
+    f.dgamma = c->st.g_grads ? GG(c, gi_bn_w(l)) : nullptr; f.dbeta = c->st.g_grads ? GG(c, gi_bn_b(l)) : nullptr;
+    return f;
+}
+
 // Generator.forward (generator_vanilla_gan.py:189-209).  training: BN batch stats (+ running
 // update) and raw pre-BN outputs kept for the backward pass; eval: BN folded into the epilogue.
 // z == nullptr: the latent batch is drawn inside the fc kernel from RNG stream rng_sid and left in z_out.
@@ -671,14 +695,16 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
         const int C = Co;
         const int64_t off = c->g_bn_off[l];
         if (training) {
-            a.out = c->g_y[l]; a.epi = EPI_RAW;
-            launch_gconv(a, s);
+            // the block's batch statistics ride in the GEMM's epilogue and its last workgroup writes the table and the running
+            // statistics (EPI_BN_FWD_STATS, xacc.h): no reduction pass over y, no finalize launch
             const int64_t R = (int64_t)B * 4 * Hi * Hi;
+            a.out = c->g_y[l]; a.epi = EPI_BN_FWD_STATS; a.fin = bn_fin(c, l, 1, R);
+            if (!launch_gconv(a, s))       // (every tile configuration of this model takes the epilogue; the generic pass stays for any that does not)
+                launch_bn_train_stats(c->dt, c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
+                                      c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
+                                      BN_MOMENTUM, BN_EPS, s);
             // the LAST block's activation has two readers, the final conv here and its weight gradient in the backward
             // pass: both re-derive it from y and this table, so it is never written (33.5 MB each way at batch 64)
-            launch_bn_train_stats(c->dt, c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
-                                  c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
-                                  BN_MOMENTUM, BN_EPS, s);
             if (l < c->Lg) launch_bn_relu(c->dt, c->g_y[l], A[l], R, C, c->g_bn[l], s);
         } else {
             a.out = A[l]; a.epi = EPI_AFFINE_RELU; a.scale = c->g_bne[l]; a.shift = c->g_bne[l] + C;
@@ -823,18 +849,19 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
 // BatchNorm backward and the input-gradient chain; lane a: the weight gradients.
 static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     const int Lg = c->Lg, S = c->S;
-    int pre_rows = 0;              // partial rows of block l's BatchNorm-backward sums left by the input-gradient GEMM of block l+1
+    int stats_done = 0;            // block l's BatchNorm-backward sums were finalized by the input-gradient GEMM of block l+1
     for (int l = Lg; l >= 1; --l) {
         const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
         const int64_t R = (int64_t)B * Ho * Ho;
         if (l == Lg) {   // final conv's input-gradient folded into this block's BatchNorm backward; its weight gradient rides in
-                         // the same pass over y and its row sums stay on this lane (a 5 us kernel does not pay for a fork + join)
-            launch_final_bwd_reduce(c->dt, c->dpre, c->wfin_t, c->g_y[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b, L.m);
-            launch_final_bn_bwd_apply(c->dt, c->dpre, c->wfin_t, c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b,
-                                      GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
+                         // the same pass over y; the sums are finalized by that launch's last workgroup (xacc.h)
+            launch_final_bwd_reduce(c->dt, c->dpre, c->wfin_t, c->g_y[l], B, S, Co, c->g_bn[l], bn_fin(c, l, 2, R), c->partial_b, L.m);
+            launch_final_bn_bwd_apply(c->dt, c->dpre, c->wfin_t, c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], L.m);
         } else
-            launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m, pre_rows);
+            launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m, stats_done != 0);
         L.fork(L.a);                                       // dy[l] is complete on m here
+        if (l == Lg)     // the final conv's weight / bias gradient from the rows k_final_bwd_reduce left: nothing on this chain reads it
+            launch_final_wsum(c->partial_b, B, S, Co, GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), L.a);
         // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
         // (one fork per block; per two blocks measured the same, weight gradients on the main lane 2.5 % slower: DESIGN 4)
         WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
@@ -848,9 +875,9 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
         a.B = B; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
         if (l >= 2) {              // its output is d(relu output) of block l-1: that block's BatchNorm-backward sums ride in the epilogue
-            a.epi = EPI_BN_BWD_STATS; a.aref = c->g_y[l - 1]; a.bnp = c->g_bn[l - 1]; a.stat0 = c->partial;
+            a.epi = EPI_BN_BWD_STATS; a.aref = c->g_y[l - 1]; a.bnp = c->g_bn[l - 1]; a.fin = bn_fin(c, l - 1, 2, (int64_t)B * Hi * Hi);
         }
-        pre_rows = launch_gconv(a, L.m);
+        stats_done = launch_gconv(a, L.m);
     }
     if (!(c->fc_fused && launch_fc_bwd_fused(c->dt, c->g_da[0], c->fc_y, z, c->g_bn[0], GG(c, gi_fc_w()), GG(c, gi_fc_b()),
                                              GG(c, gi_bn0_w()), GG(c, gi_bn0_b()), B, c->latent, c->gC[0], L.m))) {
@@ -931,6 +958,7 @@ static void phase_d_grads_sn(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
 }
 
 static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
+    c->early_ar = false;             // set again by this pass when (and only when) it starts the tail's all-reduce itself
     if (c->sn) return phase_d_grads_sn(c, L, k);
     const int B = k.B;
     const bool drop = c->cfg.dropout > 0.f;
@@ -985,8 +1013,12 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // scratch).  It forks HERE but is enqueued after D(fake), whose kernels the dispatcher should see first.
     hipEvent_t e_spec = nullptr;
     if (spec_fwd && !spec_early) { e_spec = L.next(); L.record(e_spec, L.m); }
+    // the staged D(real) launch (lane c, previous G step) also drew THIS pass' dropout tables (dreal_noise2): the main lane
+    // must be behind that lane before D(fake) reads them, not only before the backward pass reads the rows
+    const bool join_early = k.pre_real == 2 && !c->dreal_joined && drop && c->dreal_noise2;
+    if (join_early) L.wait(L.m, c->ev_dreal);
     d_forward_rows(c, fake, B, B, drop, L.m, c->slab_k, true);       // D(fake) into rows [B, 2B)
-    if (k.pre_real == 2 && !c->dreal_joined) L.wait(L.m, c->ev_dreal);
+    if (k.pre_real == 2 && !c->dreal_joined && !join_early) L.wait(L.m, c->ev_dreal);
     c->dreal_joined = c->dreal_noise2 = false;
     if (spec_fwd && !spec_early) {
         L.wait(c->s_c, e_spec);
@@ -1108,7 +1140,8 @@ static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         // ONE launch: the host knows the step count (apply_common), so the bias corrections are kernel arguments and
         // k_adam_prepare (a 5 us kernel plus a kernel boundary on the step's critical lane, twice per step) is not needed
         launch_adam_fused(p, g, m, v, n, c->dev, steps, nt, k.fused_t, k.lr, k.beta1, k.beta2, k.eps, gs, k.clip,
-                          k.mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), clip ? c->partial : nullptr, L.m);
+                          k.mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), clip ? c->partial : nullptr, L.m,
+                          k.mt + (which == 0 ? SIGGAN_M_G_SKIPPED : SIGGAN_M_D_SKIPPED));
         return;
     }
     launch_adam_prepare(c->dev, steps, nt, k.lr, k.beta1, k.beta2, gs, k.clip,
@@ -1286,7 +1319,7 @@ static int d_grads_common(siggan_ctx* c, const float* real_dev, int32_t batch, c
     PhaseKey k = make_key(c, 0, B, z_dev != nullptr, masks_dev != nullptr, hp, metrics_dev);
     c->metrics_last = k.mt;
     k.spec_g = spec_g; k.has_zg = spec_g && zg_dev != nullptr; k.pre_real = pre_real; k.variant = c->variant;
-    k.coll = apply_follows && c->comm != nullptr;
+    k.coll = apply_follows && c->comm != nullptr && (c->mode & SIGGAN_MODE_GRAPH) == 0;   // (no collective inside a captured phase)
     if ((rc = run_phase(c, k, s))) return rc;
     c->g_dirty = c->d_dirty = false;
     if (spec_g) { c->g_fwd_pending = B; c->g_dirty = true; }   // running statistics moved
@@ -1519,7 +1552,7 @@ extern "C" int siggan_comm_destroy(siggan_ctx* c) {
     if (!c->comm) return SIGGAN_OK;
     HIPCHK(hipDeviceSynchronize());
     NCCLCHK(rccl()->CommDestroy(c->comm));
-    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1; c->comm_err = 0;
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1; c->comm_err = 0; c->early_ar = false;
     return SIGGAN_OK;
 }
 extern "C" int32_t siggan_comm_world(const siggan_ctx* c) { return c ? c->comm_world : -1; }

@@ -19,12 +19,14 @@ from oracle import siggan_oracle as O                # noqa: E402  (the checker)
 GOLDEN = os.path.join(HERE, "golden")
 CASES = [(64, 100, 4), (64, 100, 64), (128, 128, 4), (128, 128, 32), (64, 100, 128),   # (64, 100, 128): BASELINE configs[3]
          (64, 100, 5),      # an odd batch: ragged row tiles in every GEMM, five samples per BatchNorm statistic
-         (128, 128, 5)]     # the same at 128x128 (five blocks per network, the 64-channel patch kernel)
+         (128, 128, 5),     # the same at 128x128 (five blocks per network, the 64-channel patch kernel)
+         (64, 50, 8)]       # latent_dim % 4 != 0 (the ablation grid's z = 50): the Generator fc's generic (non-MFMA) kernels
 SEED = dict(state_g=101, state_d=202, adam_g=303, adam_d=404, z=11, real=22)
 
 
-def load_golden(size, batch):
-    f = np.load(os.path.join(GOLDEN, f"golden_s{size}_b{batch}.npz"))
+def load_golden(size, batch, latent=None):
+    z = "" if latent in (None, 100 if size == 64 else 128) else f"_z{latent}"
+    f = np.load(os.path.join(GOLDEN, f"golden_s{size}{z}_b{batch}.npz"))
     meta = json.loads(str(f["meta"]))
     return f, meta
 

@@ -283,7 +283,8 @@ def make(size, latent, B, full_image):
         assert acts.same_as(census["gstep"]), "the G-step forward differs between the step variants"
         record_step(f"gstep_{tag}", m, m.generator, m.g_optimizer, met, out, extra_buffers=True)
 
-    # (viii) 3-step sequence (D then G each step), metrics only ---------------------------
+    # (viii) 3-step sequence (D then G each step): metrics, and every half-step's census (seq3/d<s>, seq3/g<s>) so that the
+    # chained steps can be compared decision for decision like the single ones
     m = fresh_model(size, latent, warm=True)
     tap = MaskTap(m.discriminator)
     torch.manual_seed(SEED_TORCH + 2)
@@ -291,8 +292,12 @@ def make(size, latent, B, full_image):
     for s in range(3):
         zs = torch.from_numpy(I.gen_z(B, latent, 1000 + 2 * s))
         zg = torch.from_numpy(I.gen_z(B, latent, 1001 + 2 * s))
+        acts = ActTap(m.discriminator)
         dm = m.train_discriminator_step(real, noise=zs)
+        acts.close(); acts.store(f"seq3/d{s}", out)
+        acts = ActTap(m.generator, m.discriminator)
         gm = m.train_generator_step(B, noise=zg)
+        acts.close(); acts.store(f"seq3/g{s}", out)
         seq.append([dm["d_loss"], dm["d_loss_real"], dm["d_loss_fake"], dm["d_real_mean"],
                     dm["d_fake_mean"], gm["g_loss"], gm["g_fake_mean"]])
     tap.close()
@@ -304,9 +309,15 @@ def make(size, latent, B, full_image):
         "batch": B, "clip": CLIP, "census_rel": CENSUS_REL,
         "seeds": dict(state_g=SEED_STATE_G, state_d=SEED_STATE_D, adam_g=SEED_ADAM_G, adam_d=SEED_ADAM_D,
                       z=SEED_Z, real=SEED_REAL, torch=SEED_TORCH)}))
-    path = os.path.join(HERE, f"golden_s{size}_b{B}.npz")
+    path = os.path.join(HERE, golden_name(size, latent, B))
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def golden_name(size, latent, B):
+    """The latent size is part of the name only when it is not the model's default (100 at 64x64, 128 at 128x128)."""
+    z = "" if latent == (100 if size == 64 else 128) else f"_z{latent}"
+    return f"golden_s{size}{z}_b{B}.npz"
 
 
 def make_spectral_norm():
@@ -494,6 +505,8 @@ if __name__ == "__main__":
     make(64, 100, 5, full_image=False)            # an odd batch (ragged tiles)
     make(128, 128, 5, full_image=False)           # ... at 128x128 (batch 3 was tried: three samples per BatchNorm statistic put the rounding
                                                   # noise of the exactly-zero fc bias gradient over the fixed bounds)
+    make(64, 50, 8, full_image=False)             # a latent size of the ablation grid (ablation_vanilla_gan_signatures.py:597) that is not a
+                                                  # multiple of 4: the Generator fc's generic kernels (generator_vanilla_gan.py:99,125)
     if "--cases-only" in sys.argv:                # the five step fixtures only (e.g. after adding a record to them)
         sys.exit(0)
     make_spectral_norm()

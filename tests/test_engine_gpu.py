@@ -35,11 +35,10 @@ def _scale_close(got, want, what, rt=RT):
     assert err <= rt * scale, f"{what}: max err {err:.3e}, scale {scale:.3e}"
 
 
-@pytest.mark.parametrize("size,latent,batch", CASES)
-def test_forward_vs_oracle_and_golden(size, latent, batch):
+def _forward_case(size, latent, batch, max_batch=None):
     from hipcommon import cuda, make_engine
-    f, _ = load_golden(size, batch)
-    eng = make_engine(size, latent, batch)
+    f, _ = load_golden(size, batch, latent)
+    eng = make_engine(size, latent, max_batch or batch)
     z = torch.from_numpy(I.gen_z(batch, latent, SEED["z"]))
     real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
     g_sd, d_sd, _, _ = oracle_states(size, latent, warm=False)
@@ -69,6 +68,22 @@ def test_forward_vs_oracle_and_golden(size, latent, batch):
     p = eng.d_forward(cuda(real), training=True, masks=masks)
     _scale_close(p.cpu().reshape(-1).numpy(), f["d_train/probs"], "D train probs vs golden")
     eng.close()
+
+
+@pytest.mark.parametrize("size,latent,batch", CASES)
+def test_forward_vs_oracle_and_golden(size, latent, batch):
+    _forward_case(size, latent, batch)
+
+
+# A context created for more than 256 images (siggan_create: max_batch) runs Generator.fc -- generator_vanilla_gan.py:124-128 --
+# through the generic kernels (k_fc_fwd / k_fc_wgrad + the column reductions + the k-major weight copy of k_prepare) instead of
+# the one-launch MFMA kernels, whatever the batch of the call; so does a latent size that is not a multiple of 4 (CASES' last
+# entry: z = 50 of the ablation grid, ablation_vanilla_gan_signatures.py:597).  Same fixtures, same bars.
+BIG_CTX = 320
+
+
+def test_forward_in_a_context_for_320_images():
+    _forward_case(64, 100, 64, max_batch=BIG_CTX)
 
 
 from hipcommon import count_sign_flips, hip_signs_d, hip_signs_g  # noqa: E402  (sign decisions of the HIP path, shared with smoke())
@@ -215,11 +230,11 @@ def _reference_chain(which, f, tag, step, eng, met, hip_signs, run_oracle, init_
     return row
 
 
-@pytest.mark.parametrize("size,latent,batch", CASES)
-@pytest.mark.parametrize("tag", ["warm", "fresh", "clip"])
-def test_single_steps(size, latent, batch, tag):
+def _single_steps(size, latent, batch, tag, max_batch=None):
     from hipcommon import cuda, make_engine
-    f, meta = load_golden(size, batch)
+    f, meta = load_golden(size, batch, latent)
+    key = f"s{size}_b{batch}" + ("" if latent in (100, 128) else f"_z{latent}") + (f"_ctx{max_batch}" if max_batch else "")
+    max_batch = max_batch or batch
     clip = meta["clip"] if tag == "clip" else None
     warm = tag != "fresh"
     z = torch.from_numpy(I.gen_z(batch, latent, SEED["z"]))
@@ -229,7 +244,7 @@ def test_single_steps(size, latent, batch, tag):
     nb = len(masks) // 2
 
     # ---- D step ------------------------------------------------------------------------
-    eng = make_engine(size, latent, batch, warm=warm)
+    eng = make_engine(size, latent, max_batch, warm=warm)
     met = eng.d_step(cuda(real), cuda(z), masks, clip=clip)
 
     def oracle_d(signs, rec):
@@ -237,13 +252,13 @@ def test_single_steps(size, latent, batch, tag):
         o_met, o_grads = O.d_step(g_sd, d_sd, d_opt, real, z, masks[:nb], masks[nb:], size, clip=clip, signs=signs, record=rec)
         return o_met, o_grads, d_sd, d_opt
     _, i_d, _, i_dopt = oracle_states(size, latent, warm=warm)
-    MARGINS[f"s{size}_b{batch}/{tag}/d"] = _reference_chain("d", f, f"dstep_{tag}", "dstep", eng, met, hip_signs_d(eng, size, batch, 2),
+    MARGINS[f"{key}/{tag}/d"] = _reference_chain("d", f, f"dstep_{tag}", "dstep", eng, met, hip_signs_d(eng, size, batch, 2),
                                                             oracle_d, i_d, i_dopt, keep=masks)
     _dump_margins()
     eng.close()
 
     # ---- G step ------------------------------------------------------------------------
-    eng = make_engine(size, latent, batch, warm=warm)
+    eng = make_engine(size, latent, max_batch, warm=warm)
     met = eng.g_step(batch, cuda(z2), clip=clip)
     bufs = {}
 
@@ -253,7 +268,7 @@ def test_single_steps(size, latent, batch, tag):
         bufs.update({k: v for k, v in g_sd.items() if k not in g_opt.names})
         return o_met, o_grads, g_sd, g_opt
     i_g, _, i_gopt, _ = oracle_states(size, latent, warm=warm)
-    MARGINS[f"s{size}_b{batch}/{tag}/g"] = _reference_chain("g", f, f"gstep_{tag}", "gstep", eng, met,
+    MARGINS[f"{key}/{tag}/g"] = _reference_chain("g", f, f"gstep_{tag}", "gstep", eng, met,
                                                             hip_signs_g(eng, size, batch) + hip_signs_d(eng, size, batch, 1),
                                                             oracle_g, i_g, i_gopt)
     _dump_margins()
@@ -262,26 +277,118 @@ def test_single_steps(size, latent, batch, tag):
     eng.close()
 
 
-@pytest.mark.parametrize("size,latent,batch", CASES[:4])
+@pytest.mark.parametrize("size,latent,batch", CASES)
+@pytest.mark.parametrize("tag", ["warm", "fresh", "clip"])
+def test_single_steps(size, latent, batch, tag):
+    _single_steps(size, latent, batch, tag)
+
+
+@pytest.mark.parametrize("tag", ["warm", "clip"])
+def test_single_steps_in_a_context_for_320_images(tag):
+    _single_steps(64, 100, 64, tag, max_batch=BIG_CTX)
+
+
+def _oracle_state_of(eng, size, latent):
+    """The engine's complete training state as oracle dicts (copies on the CPU): g_sd (parameters + BatchNorm buffers), d_sd,
+    and both Adam states."""
+    gs, ds = O.g_state_specs(latent, size), O.d_state_specs(size)
+    cp = lambda d: {k: t.detach().float().cpu().clone() for k, t in d.items()}
+    g_par, d_par, bn = cp(eng.views("g")), cp(eng.views("d")), eng.bn_views()
+    g_sd = {}
+    for k, (_, kind) in gs.items():
+        g_sd[k] = g_par[k] if kind == "param" else (bn[k].detach().cpu().clone() if kind == "counter" else bn[k].detach().float().cpu().clone())
+    opts = []
+    for which, specs, sd in (("g", gs, g_sd), ("d", ds, d_par)):
+        o = O.AdamState(O.param_names(specs), sd)
+        o.m, o.v = cp(eng.views(which, "exp_avg")), cp(eng.views(which, "exp_avg_sq"))
+        o.step = int(float(getattr(eng, f"{which}_adam_steps")[0]))
+        opts.append(o)
+    return g_sd, d_par, opts[0], opts[1]
+
+
+def _grads_close(eng, which, o_grads, what, tol=1e-4):
+    """HIP gradient arena vs an oracle's, each tensor relative to its own scale (floored at 1e-3 of the network's; the Linear
+    bias in front of BatchNorm1d, whose true gradient is zero, at 1e-2)."""
+    gv = eng.views(which, "grads")
+    gscale = max(float(o_grads[k].abs().max()) for k in gv)
+    worst = 0.0
+    for k, t in gv.items():
+        sc = max(float(o_grads[k].abs().max()), (1e-2 if k == "fc.0.bias" else 1e-3) * gscale)
+        err = float((t.cpu() - o_grads[k]).abs().max()) / sc
+        worst = max(worst, err)
+        assert err <= tol, f"{what} grad {k}: {err:.3e} of scale {sc:.3e}"
+    return worst
+
+
+SEQ3_RT, SEQ3_AT = 1e-3, 1e-4        # the north star's 1e-3 on the chained metrics (losses / mean predictions, O(0.1 .. 1))
+
+
+@pytest.mark.parametrize("size,latent,batch", CASES)
 def test_three_step_sequence(size, latent, batch):
+    """VanillaGAN.train_step three times over (vanilla_gan_model.py:308-336), closed like the single steps:
+
+      per half-step   the HIP gradients equal oracle(the HIP path's sign decisions) run FROM THE ENGINE'S OWN STATE before that
+                      half-step, to 1e-4 of the tensor's scale, metrics to 2e-4 -- the arithmetic of every chained step;
+      the sequence    A = the HIP metrics, G = the reference's record, C = the oracle chain given the reference run's decisions
+                      (the fixture's per-half-step census; C = G to 1e-4 is asserted here and on the CPU), B = the oracle chain
+                      given the HIP path's decisions.  No differing decision: A = G at 1e-3, strictly.  Otherwise A - G must be
+                      what those decisions produce, B - C, to the same 1e-3 -- the bare 1e-2 of round 3 is gone."""
     from hipcommon import cuda, make_engine
-    f, _ = load_golden(size, batch)
-    real = cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"])))
+    f, _ = load_golden(size, batch, latent)
+    real_c = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
+    real = cuda(real_c)
     eng = make_engine(size, latent, batch, warm=True)
     masks = masks_from(f, "seq3/masks", batch, size, 6)
     nb = len(masks) // 6
-    rows = []
+    Bc, Cc = oracle_states(size, latent, warm=True), oracle_states(size, latent, warm=True)     # (g_sd, d_sd, g_opt, d_opt)
+    rows = {"A": [], "B": [], "C": []}
+    nflips, worst = 0, 0.0
+    dk = ("d_loss", "d_loss_real", "d_loss_fake", "d_real_mean", "d_fake_mean")
+    gk = ("g_loss", "g_fake_mean")
     for s in range(3):
-        zs = cuda(torch.from_numpy(I.gen_z(batch, latent, 1000 + 2 * s)))
-        zg = cuda(torch.from_numpy(I.gen_z(batch, latent, 1001 + 2 * s)))
-        dm = eng.d_step(real, zs, masks[2 * nb * s: 2 * nb * (s + 1)])
-        gm = eng.g_step(batch, zg)
-        rows.append([dm["d_loss"], dm["d_loss_real"], dm["d_loss_fake"], dm["d_real_mean"], dm["d_fake_mean"],
-                     gm["g_loss"], gm["g_fake_mean"]])
-    # the 64x64 cases hold 1e-3 over three chained Adam steps; the 128x128 cases (one more block at each end, BatchNorm over
-    # 4 / 32 samples) amplify fp32 summation-order differences step over step -- the reference itself drifts by ~1e-3 in five
-    # steps between thread counts ("Adam") -- and are held to 1e-2
-    assert_close(np.array(rows), f["seq3/metrics"], 1e-3 if size == 64 else 1e-2, 1e-4, "3-step metrics vs golden")
+        zs_c, zg_c = (torch.from_numpy(I.gen_z(batch, latent, 1000 + 2 * s + j)) for j in (0, 1))
+        ms = masks[2 * nb * s: 2 * nb * (s + 1)]
+        # ---- D half ----
+        g0, d0, _, do0 = _oracle_state_of(eng, size, latent)
+        dm = eng.d_step(real, cuda(zs_c), ms)
+        hs = hip_signs_d(eng, size, batch, 2)
+        rec = []
+        om, og = O.d_step(g0, d0, do0, real_c, zs_c, ms[:nb], ms[nb:], size, signs=hs, record=rec)
+        count_sign_flips(hs, rec, keep=ms)
+        for k in dk:
+            assert_close(dm[k], om[k], 2e-4, 2e-6, f"step {s} D metric {k} vs oracle(HIP signs) from the engine's state")
+        worst = max(worst, _grads_close(eng, "d", og, f"step {s} D"))
+        bm, _ = O.d_step(Bc[0], Bc[1], Bc[3], real_c, zs_c, ms[:nb], ms[nb:], size, signs=hs)
+        cm, _ = O.d_step(Cc[0], Cc[1], Cc[3], real_c, zs_c, ms[:nb], ms[nb:], size, signs=census_signs(f, f"seq3/d{s}"))
+        nflips += len(flips_vs_census(f, f"seq3/d{s}", hs, keep=ms))
+        # ---- G half ----
+        g0, d0, go0, _ = _oracle_state_of(eng, size, latent)
+        gm = eng.g_step(batch, cuda(zg_c))
+        hs = hip_signs_g(eng, size, batch) + hip_signs_d(eng, size, batch, 1)
+        rec = []
+        om, og = O.g_step(g0, d0, go0, zg_c, size, signs=hs, record=rec)
+        count_sign_flips(hs, rec)
+        for k in gk:
+            assert_close(gm[k], om[k], 2e-4, 2e-6, f"step {s} G metric {k} vs oracle(HIP signs) from the engine's state")
+        worst = max(worst, _grads_close(eng, "g", og, f"step {s} G"))
+        bg, _ = O.g_step(Bc[0], Bc[1], Bc[2], zg_c, size, signs=hs)
+        cg, _ = O.g_step(Cc[0], Cc[1], Cc[2], zg_c, size, signs=census_signs(f, f"seq3/g{s}"))
+        nflips += len(flips_vs_census(f, f"seq3/g{s}", hs))
+        for name, d_, g_ in (("A", dm, gm), ("B", bm, bg), ("C", cm, cg)):
+            rows[name].append([d_[k] for k in dk] + [g_[k] for k in gk])
+    A, B, Cm, G = (np.array(rows[k], np.float64) for k in "ABC") + (np.asarray(f["seq3/metrics"], np.float64),)
+    assert_close(Cm, G, 1e-4, 1e-5, "3-step metrics: oracle(reference's decisions) vs the reference")
+    row = {"flips_vs_reference": nflips, "hip_vs_oracle_with_hip_signs": worst,
+           "metrics_vs_reference": float(np.abs(A - G).max()), "predicted_by_the_flips": float(np.abs(B - Cm).max())}
+    if nflips == 0:
+        row["branch"] = "strict 1e-3 (no decision differs from the reference run)"
+        assert_close(A, G, SEQ3_RT, SEQ3_AT, "3-step metrics vs the reference")
+    else:
+        row["branch"] = f"explained by {nflips} decision(s): HIP - reference = oracle(HIP signs) - oracle(reference signs) to 1e-3"
+        row["residual"] = float(np.abs((A - G) - (B - Cm)).max())
+        assert_close(A - (B - Cm), G, SEQ3_RT, SEQ3_AT, "3-step metrics vs the reference, the differing decisions' effect removed")
+    MARGINS[f"s{size}_b{batch}" + ("" if latent in (100, 128) else f"_z{latent}") + "/seq3"] = row
+    _dump_margins()
     eng.close()
 
 

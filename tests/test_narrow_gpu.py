@@ -29,7 +29,8 @@ from common import I, O, SEED, d_chans, oracle_states
 
 pytestmark = pytest.mark.gpu
 
-CASES = [(64, 100, 4), (64, 100, 64), (128, 128, 32), (64, 100, 5)]      # last: an odd batch (ragged row tiles)
+CASES = [(64, 100, 4), (64, 100, 64), (128, 128, 32), (64, 100, 5),      # (64, 100, 5): an odd batch (ragged row tiles)
+         (64, 50, 8)]       # latent_dim % 4 != 0: the Generator fc's generic kernels in 16-bit storage
 TORCH_T = {"bf16": torch.bfloat16, "f16": torch.float16}
 # metric: relative (losses, mean predictions); image: absolute (pixels in [-1, 1]); grad_t: relative L2 error of the worst
 # parameter tensor (NAMED in the report: it is final_conv.0.bias -- one scalar, a near-cancelling sum over every pixel -- at

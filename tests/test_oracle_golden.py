@@ -11,11 +11,12 @@ from common import (CASES, I, O, SEED, ablation_groups, assert_close, census_sig
                     oracle_states, probe)
 
 RT, AT = 1e-4, 1e-6
+SEQ3_RT, SEQ3_AT = 1e-4, 1e-5     # chained metrics of the three-step sequence (losses / mean predictions, O(0.1 .. 1))
 
 
 @pytest.mark.parametrize("size,latent,batch", CASES)
 def test_forward_passes(size, latent, batch):
-    f, meta = load_golden(size, batch)
+    f, meta = load_golden(size, batch, latent)
     z = torch.from_numpy(I.gen_z(batch, latent, SEED["z"]))
     real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
     g_sd, d_sd, _, _ = oracle_states(size, latent, warm=False)
@@ -72,7 +73,7 @@ def _check_step(f, tag, names, metrics, grads, sd, opt, bufs=None):
 @pytest.mark.parametrize("size,latent,batch", CASES)
 @pytest.mark.parametrize("tag", ["warm", "fresh", "clip"])
 def test_single_steps(size, latent, batch, tag):
-    f, meta = load_golden(size, batch)
+    f, meta = load_golden(size, batch, latent)
     clip = meta["clip"] if tag == "clip" else None
     z = torch.from_numpy(I.gen_z(batch, latent, SEED["z"]))
     z2 = torch.from_numpy(I.gen_z(batch, latent, SEED["z"] + 1))
@@ -101,7 +102,7 @@ def test_census_makes_the_oracle_host_independent(size, latent, batch):
     at 128x128 batch 32; |x| ~ 1e-8 of the layer scale) and its gradients move by 1e-4..1e-3: that is the reference's noise
     against ITSELF.  Given the fixture's census the oracle must reproduce the fixture at 1e-4 whatever the thread count --
     which is what lets the GPU box's CPU (another host) anchor the HIP path to the reference run."""
-    f, _ = load_golden(size, batch)
+    f, _ = load_golden(size, batch, latent)
     z2 = torch.from_numpy(I.gen_z(batch, latent, SEED["z"] + 1))
     ref = f["gstep_warm/grad_norm"]
     big = ref > 1e-5 * ref.max()
@@ -120,10 +121,12 @@ def test_census_makes_the_oracle_host_independent(size, latent, batch):
         assert abs(v) <= 1e-5, (l, i, v)
 
 
-@pytest.mark.parametrize("size,latent,batch", CASES[:2])
+@pytest.mark.parametrize("size,latent,batch", CASES)
 def test_three_step_sequence(size, latent, batch):
-    """Loss/prediction tolerance only: Adam amplifies rounding-order differences."""
-    f, meta = load_golden(size, batch)
+    """VanillaGAN.train_step three times over (vanilla_gan_model.py:308-336).  Every half-step of the fixture carries the
+    reference run's near-zero activation census (seq3/d<s>, seq3/g<s>): given those decisions the oracle must reproduce the
+    chained metrics like the single steps -- the free-running oracle needed 1e-3 here and only held it at 64x64."""
+    f, meta = load_golden(size, batch, latent)
     real = torch.from_numpy(I.gen_real(batch, size, SEED["real"]))
     g_sd, d_sd, g_opt, d_opt = oracle_states(size, latent, warm=True)
     masks = masks_from(f, "seq3/masks", batch, size, 6)
@@ -133,11 +136,11 @@ def test_three_step_sequence(size, latent, batch):
         zs = torch.from_numpy(I.gen_z(batch, latent, 1000 + 2 * s))
         zg = torch.from_numpy(I.gen_z(batch, latent, 1001 + 2 * s))
         ms = masks[2 * nb * s: 2 * nb * (s + 1)]
-        dm, _ = O.d_step(g_sd, d_sd, d_opt, real, zs, ms[:nb], ms[nb:], size)
-        gm, _ = O.g_step(g_sd, d_sd, g_opt, zg, size)
+        dm, _ = O.d_step(g_sd, d_sd, d_opt, real, zs, ms[:nb], ms[nb:], size, signs=census_signs(f, f"seq3/d{s}"))
+        gm, _ = O.g_step(g_sd, d_sd, g_opt, zg, size, signs=census_signs(f, f"seq3/g{s}"))
         rows.append([dm["d_loss"], dm["d_loss_real"], dm["d_loss_fake"], dm["d_real_mean"],
                      dm["d_fake_mean"], gm["g_loss"], gm["g_fake_mean"]])
-    assert_close(np.array(rows), f["seq3/metrics"], 1e-3, 1e-4, "3-step metrics")
+    assert_close(np.array(rows), f["seq3/metrics"], SEQ3_RT, SEQ3_AT, "3-step metrics, oracle(reference's decisions) vs the reference")
 
 
 def test_param_counts_match_reference_manifest():
