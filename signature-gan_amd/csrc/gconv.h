@@ -7,7 +7,6 @@
 #include <vector>
 
 #include "act.h"
-#include "xacc.h"
 
 namespace siggan {
 
@@ -17,13 +16,9 @@ enum Epilogue : int {
     EPI_AFFINE_RELU,      // relu(acc * scale[c] + shift[c])           (Generator block, BN eval folded)
     EPI_LRELU_BWD,        // acc * leaky'(aref) * noise[n,c]           (Discriminator input-gradient)
     EPI_BN_BWD_STATS,     // store the accumulator AND the BatchNorm-backward sums of the tensor it is the gradient of (Generator
-                          // input-gradient): sum(dr) and sum(dr * xhat), dr = relu'(.) * acc with the mask re-derived from aref =
-                          // the pre-BatchNorm tensor y (fma(y, scale, shift) > 0, k_bn_relu's own expression) and xhat =
-                          // (y - mean) * rstd -- what k_colreduce<FBnBwd> computes in a pass of its own.  Every workgroup adds its
-                          // tile's column sums to the exact accumulators of `fin`; the last one finalizes (xacc.h)
-    EPI_BN_FWD_STATS,     // store the accumulator (the pre-BatchNorm tensor y of a training-mode Generator block) AND its batch
-                          // statistics sum(y - shift), sum((y - shift)^2) the same way: the table [scale | shift | mean | rstd] and
-                          // the running statistics are written by the launch itself -- no k_colreduce / k_bn_train_fin behind it
+                          // input-gradient): per workgroup one partial row of sum(dr) and sum(dr * xhat), dr = relu'(.) * acc with
+                          // the mask re-derived from aref = the pre-BatchNorm tensor y (fma(y, scale, shift) > 0, k_bn_relu's own
+                          // expression) and xhat = (y - mean) * rstd -- what k_colreduce<FBnBwd> computes in a pass of its own
 };
 
 // out[n, opix, co] = sum_{tap, ci} in[n, pix(tap), ci] * wp[cls][co][tap*Ci + ci]
@@ -44,8 +39,10 @@ struct GConvArgs {
     const float* shift;   // [Co]
     const void* aref;     // [B][Ho][Wo][Co] stored activation (EPI_LRELU_BWD) / pre-BatchNorm tensor (EPI_BN_BWD_STATS)
     const float* bnp;     // EPI_BN_BWD_STATS: [scale | shift | mean | rstd] of the output's BatchNorm, Co floats each
-    BnFin fin;            // EPI_BN_BWD_STATS / EPI_BN_FWD_STATS: accumulators, ticket and what the last workgroup finalizes (xacc.h);
-                          //   launch_gconv returns 1 when the launch (or its split-K epilogue) did it
+    float* stat0;         // EPI_BN_BWD_STATS: partial rows [nrows][Co] of sum(dr); launch_gconv returns nrows and puts the
+    float* stat1;         //   rows of sum(dr * xhat) right behind them (stat1 = stat0 + nrows * Co, filled by launch_gconv)
+    int64_t stat_cap;     //   floats available at stat0: a launch whose 2 * nrows * Co rows would not fit stores the raw accumulator
+                          //   instead (EPI_RAW) and returns 0 -- the caller then runs the generic reduction pass (k_colreduce)
     const float* cls_w;   // optional (last Discriminator block): the classifier's weight in the output's own (NHWC) order, Ho*Wo*Co
     float* cls_part;      //   floats.  When the launch ends in k_splitk_epilogue, each of its workgroups also writes the partial
                           //   dot product of its 1024 stored output values with cls_w to cls_part[workgroup] (P = Ho*Wo*Co / 1024
@@ -79,16 +76,6 @@ __device__ __forceinline__ void bn_bwd_stat_terms(const f32x4 v, const f32x4 y, 
     }
 }
 
-// EPI_BN_FWD_STATS, one float4 of the output: v as it is stored (rounded to T), sh = the channels' shift
-template <class T>
-__device__ __forceinline__ void bn_fwd_stat_terms(const f32x4 v, const f32x4 sh, f32x4& s0, f32x4& s1) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float d = (float)(T)v[e] - sh[e];
-        s0[e] += d;
-        s1[e] = fmaf(d, d, s1[e]);
-    }
-}
 // slab[z][i][tap*Cl + l] = sum_{pix in split z} S[pix][i] * L[n, 2p-1+kh, 2q-1+kw][l]
 struct WgradArgs {
     int dt;               // element type of S and L; slab / dw / db are always fp32
@@ -117,7 +104,7 @@ struct Prof {
 };
 extern Prof* g_prof;
 
-// returns 1 when a statistics epilogue ran and finalized (EPI_BN_*_STATS), the classifier's partial count P with cls_w, else 0
+// returns the number of partial rows written to stat0 / stat1 (EPI_BN_BWD_STATS), 0 otherwise
 int launch_gconv(const GConvArgs& a, hipStream_t st);
 // 16-bit operand kernels (gconv16.hip); cfg: 0 = 128x128, 2 = 64x64, 3 = 128x32 tiles; e0 / e1: optional timing events
 void launch_gconv16(int cfg, const GConvArgs& a, dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int kq = 1);

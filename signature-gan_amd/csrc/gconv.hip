@@ -283,15 +283,13 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv(const GConvArgs a) {
                     sT[(wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDT + wn * (32 * TN) + 32 * j + li] = acc[i][j][r];
     }
     __syncthreads();
-    const bool stats = epi == EPI_BN_BWD_STATS || epi == EPI_BN_FWD_STATS;
-    if (quad != 0 && !stats) return;                 // (with the statistics every wave stays for the barriers below)
+    if (quad != 0 && epi != EPI_BN_BWD_STATS) return;       // (with the statistics every wave stays for the barriers below)
     constexpr int C4 = BN / 4, RPP = 256 / C4;       // float4 columns per row, rows per pass
     const int c4 = tid % C4, r0 = tid / C4;
     const int co = n0 + c4 * 4;
     BnBwdParams bq;
-    f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = st0, shf = st0;
+    f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = st0;
     if (epi == EPI_BN_BWD_STATS) bq = bn_bwd_params(a.bnp, a.Co, co);
-    if (epi == EPI_BN_FWD_STATS) shf = *reinterpret_cast<const f32x4*>(a.fin.rmean + co);
     const f32x4 bias4 = epi == EPI_BIAS_LRELU_DROP ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
     if (epi == EPI_AFFINE_RELU) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + co); sh4 = *reinterpret_cast<const f32x4*>(a.shift + co); }
@@ -312,8 +310,6 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv(const GConvArgs a) {
         f32x4 v = *reinterpret_cast<const f32x4*>(sT + row * LDT + c4 * 4);
         if (epi == EPI_BN_BWD_STATS) {
             bn_bwd_stat_terms<float>(v, *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.aref) + o), bq, st0, st1);
-        } else if (epi == EPI_BN_FWD_STATS) {
-            bn_fwd_stat_terms<float>(v, shf, st0, st1);
         } else if (epi == EPI_BIAS_LRELU_DROP) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { float t = v[e] + bias4[e]; v[e] = t > 0.f ? t : t * a.slope; }
@@ -337,26 +333,25 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv(const GConvArgs a) {
         }
         *reinterpret_cast<f32x4*>(outp + o) = v;
     }
-    if (stats) {
+    if (epi == EPI_BN_BWD_STATS) {
         // the tile's column sums: the RPP row lanes of a channel group meet in LDS (the tile is stored: sT is free after the
-        // barrier) and are added in lane order; the sums go to the layer's exact accumulators and the workgroup that arrives
-        // last writes the layer's table (xacc.h) -- no partial rows, no finalize launch
-        __shared__ unsigned s_flag;
+        // barrier) and are added in lane order -- one partial row per workgroup, a fixed sum order
         __syncthreads();
         if (quad == 0) {
             *reinterpret_cast<f32x4*>(sT + (size_t)tid * 8) = st0;
             *reinterpret_cast<f32x4*>(sT + (size_t)tid * 8 + 4) = st1;
         }
         __syncthreads();
-        const bool owner = quad == 0 && r0 == 0;
-        if (owner) {
+        if (quad == 0 && r0 == 0) {
 #pragma unroll 4
             for (int k = 1; k < RPP; ++k) {
                 st0 += *reinterpret_cast<const f32x4*>(sT + (size_t)(k * C4 + c4) * 8);
                 st1 += *reinterpret_cast<const f32x4*>(sT + (size_t)(k * C4 + c4) * 8 + 4);
             }
+            const size_t prow = (size_t)cls * (gridDim.x / tiles_n) + bid / tiles_n;
+            *reinterpret_cast<f32x4*>(a.stat0 + prow * a.Co + co) = st0;
+            *reinterpret_cast<f32x4*>(a.stat1 + prow * a.Co + co) = st1;
         }
-        bn_stats_commit(a.fin, a.Co, co, owner, st0, st1, gridDim.x * gridDim.y * gridDim.z, &s_flag);
     }
 }
 
@@ -489,9 +484,6 @@ __global__ __launch_bounds__(256) void k_gconv_up4(const GConvArgs a) {
     const float sc = a.epi == EPI_AFFINE_RELU ? a.scale[li] : 1.f, sf = a.epi == EPI_AFFINE_RELU ? a.shift[li] : 0.f;
     const int Wo = 2 * Wr;
     float* const so = smem;                              // 128 * 4 * 32 floats; the main loop's last barrier has passed
-    const bool stats = a.epi == EPI_BN_FWD_STATS;        // (training forward: the block's batch statistics ride along, xacc.h)
-    const float shift = stats ? a.fin.rmean[li] : 0.f;
-    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -500,7 +492,6 @@ __global__ __launch_bounds__(256) void k_gconv_up4(const GConvArgs a) {
         for (int cls = 0; cls < 4; ++cls) {
             float v = acc[cls][r];
             if (a.epi == EPI_AFFINE_RELU) v = fmaxf(fmaf(v, sc, sf), 0.f);
-            if (stats) { const float d = v - shift; s0 += d; s1 = fmaf(d, d, s1); }
             so[(((2 * rl + (cls >> 1)) * Wo) + 2 * rw + (cls & 1)) * BN + li] = v;
         }
     }
@@ -509,35 +500,16 @@ __global__ __launch_bounds__(256) void k_gconv_up4(const GConvArgs a) {
     const f32x4* const src = reinterpret_cast<const f32x4*>(so);
 #pragma unroll
     for (int q = 0; q < (BM * 4 * BN / 4) / 256; ++q) dst[q * 256 + tid] = src[q * 256 + tid];
-    if (stats) {
-        // a lane holds channel li of 16 rows x 4 classes; its (wave, lane half) partners meet in LDS, added in that order
-        __shared__ unsigned s_flag;
-        __syncthreads();                                 // (every thread has read `so`)
-        so[(wave * 2 + lh) * BN + li] = s0;
-        so[8 * BN + (wave * 2 + lh) * BN + li] = s1;
-        __syncthreads();
-        const bool owner = tid < BN / 4;
-        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
-        if (owner) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                t0 += *reinterpret_cast<const f32x4*>(so + k * BN + tid * 4);
-                t1 += *reinterpret_cast<const f32x4*>(so + 8 * BN + k * BN + tid * 4);
-            }
-        }
-        bn_stats_commit(a.fin, BN, tid * 4, owner, t0, t1, gridDim.x, &s_flag);
-    }
 }
 
 // split-K tail: out = epilogue(sum_z slab[z]) over the NHWC output (4 channels per thread)
 template <class T>
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int nsplit, int64_t total4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (a.epi == EPI_BN_BWD_STATS || a.epi == EPI_BN_FWD_STATS) {
+    if (a.epi == EPI_BN_BWD_STATS) {
         // 256 consecutive float4 = 256 / C4 rows of all C4 channel groups (launch_gconv checks C4 | 256): the row lanes of a
-        // group meet in LDS (lane order), the workgroup's sums go to the exact accumulators, the last workgroup finalizes
+        // group meet in LDS, one partial row per workgroup, a fixed sum order
         __shared__ __attribute__((aligned(16))) float sh[256 * 8];
-        __shared__ unsigned s_flag;
         const int C4 = a.Co / 4, c4 = threadIdx.x & (C4 - 1);
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
         if (i < total4) {
@@ -545,23 +517,20 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const GConvArgs a, int 
             const size_t stride4 = a.slab_stride / 4;
             f32x4 v = sl[i];
             for (int z = 1; z < nsplit; ++z) v += sl[(size_t)z * stride4 + i];
-            if (a.epi == EPI_BN_BWD_STATS)
-                bn_bwd_stat_terms<T>(v, ld4<T>(static_cast<const T*>(a.aref) + i * 4), bn_bwd_params(a.bnp, a.Co, c4 * 4), s0, s1);
-            else
-                bn_fwd_stat_terms<T>(v, *reinterpret_cast<const f32x4*>(a.fin.rmean + c4 * 4), s0, s1);
+            bn_bwd_stat_terms<T>(v, ld4<T>(static_cast<const T*>(a.aref) + i * 4), bn_bwd_params(a.bnp, a.Co, c4 * 4), s0, s1);
             st4<T>(static_cast<T*>(a.out) + i * 4, v);
         }
         *reinterpret_cast<f32x4*>(sh + threadIdx.x * 8) = s0;
         *reinterpret_cast<f32x4*>(sh + threadIdx.x * 8 + 4) = s1;
         __syncthreads();
-        const bool owner = (int)threadIdx.x < C4;
-        if (owner) {
+        if ((int)threadIdx.x < C4) {
             for (int k = 1; k < 256 / C4; ++k) {
                 s0 += *reinterpret_cast<const f32x4*>(sh + (k * C4 + c4) * 8);
                 s1 += *reinterpret_cast<const f32x4*>(sh + (k * C4 + c4) * 8 + 4);
             }
+            *reinterpret_cast<f32x4*>(a.stat0 + (size_t)blockIdx.x * a.Co + c4 * 4) = s0;
+            *reinterpret_cast<f32x4*>(a.stat1 + (size_t)blockIdx.x * a.Co + c4 * 4) = s1;
         }
-        bn_stats_commit(a.fin, a.Co, c4 * 4, owner, s0, s1, gridDim.x, &s_flag);
         return;
     }
     if (i >= total4) return;
@@ -655,14 +624,16 @@ static int launch_cfg(const GConvArgs& a_in, hipStream_t st, int id, int nsplit)
     const int ncls = a.form == 0 ? 1 : 4;
     const int64_t total4 = (int64_t)a.B * a.Ho * a.Wo * a.Co / 4;
     int rows = 0;
-    if (a.epi == EPI_BN_BWD_STATS || a.epi == EPI_BN_FWD_STATS) {
-        // k_splitk_epilogue takes its statistics over whole rows per workgroup
+    if (a.epi == EPI_BN_BWD_STATS) {
+        // one partial row per workgroup of whichever kernel runs the epilogue; k_splitk_epilogue needs whole rows per workgroup
         if (nsplit > 1 && (256 % (a.Co / 4)) != 0) nsplit = 1;
-        rows = 1;
+        rows = nsplit > 1 ? (int)((total4 + 255) / 256) : ((a.M + BM - 1) / BM) * ncls;
+        if ((int64_t)2 * rows * a.Co > a.stat_cap) { a.epi = EPI_RAW; rows = 0; }     // (a batch whose partial rows outgrow the carve)
+        else a.stat1 = a.stat0 + (size_t)rows * a.Co;
     }
     if (a.cls_w) {
         const int64_t per_img4 = (int64_t)a.Ho * a.Wo * a.Co / 4;
-        if (nsplit > 1 && rows == 0 && total4 % 256 == 0 && per_img4 % 256 == 0) rows = (int)(per_img4 / 256);
+        if (nsplit > 1 && a.epi != EPI_BN_BWD_STATS && total4 % 256 == 0 && per_img4 % 256 == 0) rows = (int)(per_img4 / 256);
         else a.cls_w = nullptr;
     }
     dim3 grid(tiles, nsplit, ncls);
@@ -713,7 +684,7 @@ int launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         if (ns == 2 && (nk & 1) == 0) return launch_cfg<64, 64, 2, 2, 32, 1, 2>(a, st, 2, 1);
         return launch_cfg<64, 64, 2, 2, 32, 1>(a, st, 2, ns);
     }
-    if (a.dt == DT_F32 && a.form == 1 && a.Co == 32 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU || a.epi == EPI_BN_FWD_STATS) && (a.Ci == 32 || a.Ci == 64) &&
+    if (a.dt == DT_F32 && a.form == 1 && a.Co == 32 && (a.epi == EPI_RAW || a.epi == EPI_AFFINE_RELU) && (a.Ci == 32 || a.Ci == 64) &&
         a.M / 128 >= (a.Ci == 32 ? 384 : 768) && a.M % 128 == 0 &&
         ((1 << (a.lgHr + a.lgWr)) % 128) == 0 && a.lgWr >= 4 && a.lgWr <= 6) {
         // all four parity classes per workgroup, input patch resident in LDS (k_gconv_up4): the short-K Generator blocks
@@ -722,7 +693,7 @@ int launch_gconv(const GConvArgs& a_in, hipStream_t st) {
         hipEvent_t e0 = g_prof ? g_prof->recs.back().e0 : nullptr, e1 = g_prof ? g_prof->recs.back().e1 : nullptr;
         if (a.Ci == 32) hipExtLaunchKernelGGL(k_gconv_up4<32>, grid, dim3(256), 0, st, e0, e1, 0, a);
         else hipExtLaunchKernelGGL(k_gconv_up4<64>, grid, dim3(256), 0, st, e0, e1, 0, a);
-        return a.epi == EPI_BN_FWD_STATS ? 1 : 0;
+        return 0;
     }
     const int ns = splits(blocks(128, 32));
     return launch_cfg<128, 32, 4, 1, 32, 1>(a, st, 3, ns);   // Co == 32

@@ -228,9 +228,8 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv16(const GConvArgs a) {
     if (epi == EPI_AFFINE_RELU) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + co); sh4 = *reinterpret_cast<const f32x4*>(a.shift + co); }
     const bool use_noise = (epi == EPI_BIAS_LRELU_DROP || epi == EPI_LRELU_BWD) && a.noise != nullptr;
     BnBwdParams bq;
-    f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = st0, shf = st0;
+    f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = st0;
     if (epi == EPI_BN_BWD_STATS) bq = bn_bwd_params(a.bnp, a.Co, co);
-    if (epi == EPI_BN_FWD_STATS) shf = *reinterpret_cast<const f32x4*>(a.fin.rmean + co);
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
         if (q) __syncthreads();
@@ -261,8 +260,6 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv16(const GConvArgs a) {
             f32x4 v = *reinterpret_cast<const f32x4*>(sT + row * LDT + c4 * 4);
             if (epi == EPI_BN_BWD_STATS) {
                 bn_bwd_stat_terms<T>(v, ld4<T>(aref + o), bq, st0, st1);      // (v as it is stored: rounded to T)
-            } else if (epi == EPI_BN_FWD_STATS) {
-                bn_fwd_stat_terms<T>(v, shf, st0, st1);
             } else if (epi == EPI_BIAS_LRELU_DROP) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { float t = v[e] + bias4[e]; v[e] = t > 0.f ? t : t * a.slope; }
@@ -287,23 +284,23 @@ __global__ __launch_bounds__(256 * KQ) void k_gconv16(const GConvArgs a) {
             if (to_slab) *reinterpret_cast<f32x4*>(slab + o) = v; else st4<T>(outp + o, v);
         }
     }
-    if (epi == EPI_BN_BWD_STATS || epi == EPI_BN_FWD_STATS) {     // the tile's column sums -> exact accumulators -> last-arriver finalize: see k_gconv
-        __shared__ unsigned s_flag;
+    if (epi == EPI_BN_BWD_STATS) {                   // the tile's column sums: see k_gconv
         __syncthreads();
         if (quad == 0) {
             *reinterpret_cast<f32x4*>(sT + (size_t)tid * 8) = st0;
             *reinterpret_cast<f32x4*>(sT + (size_t)tid * 8 + 4) = st1;
         }
         __syncthreads();
-        const bool owner = quad == 0 && r0 == 0;
-        if (owner) {
+        if (quad == 0 && r0 == 0) {
 #pragma unroll 4
             for (int k = 1; k < RPP; ++k) {
                 st0 += *reinterpret_cast<const f32x4*>(sT + (size_t)(k * C4 + c4) * 8);
                 st1 += *reinterpret_cast<const f32x4*>(sT + (size_t)(k * C4 + c4) * 8 + 4);
             }
+            const size_t prow = (size_t)cls * (gridDim.x / tiles_n) + bid / tiles_n;
+            *reinterpret_cast<f32x4*>(a.stat0 + prow * a.Co + co) = st0;
+            *reinterpret_cast<f32x4*>(a.stat1 + prow * a.Co + co) = st1;
         }
-        bn_stats_commit(a.fin, a.Co, co, owner, st0, st1, gridDim.x * gridDim.y * gridDim.z, &s_flag);
     }
 }
 

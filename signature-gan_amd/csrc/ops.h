@@ -4,7 +4,6 @@
 #include <stdint.h>
 
 #include "act.h"
-#include "xacc.h"
 
 namespace siggan {
 
@@ -89,9 +88,8 @@ void launch_bn_train_stats(int dt, const void* y, int64_t R, int C, const float*
 void launch_bn_relu(int dt, const void* y, void* a, int64_t R, int C, const float* bn, hipStream_t s);
 // backward through relu(BN(y)): da (in) -> dy (in place); dgamma/dbeta (torch order) written.  The relu mask is
 // re-derived from y and the layer's scale/shift (the forward's own expression), so the activation is not read.
-// stats_done: the kernel that produced da already left the two means, dgamma and dbeta (gconv's EPI_BN_BWD_STATS): apply only
 void launch_bn_bwd(int dt, void* da, const void* y, int64_t R, int C, float* bn, float* partial,
-                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s, bool stats_done = false);
+                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s, int pre_rows = 0);
 
 // final 3x3 conv (C->1) + tanh, and its backward pieces.  act: [B][S][S][C] NHWC, img [B][S][S].
 // bn != nullptr (training): `act` is the last block's PRE-BatchNorm tensor y and bn its [scale | shift] table -- the
@@ -99,14 +97,13 @@ void launch_bn_bwd(int dt, void* da, const void* y, int64_t R, int C, float* bn,
 void launch_final_fwd(int dt, const void* act, const float* Wt, const float* b, float* img, int B, int S, int C, hipStream_t s,
                       const float* bn = nullptr);
 // backward of the last Generator block from dpre.  (1) launch_final_bwd_reduce: ONE read of y gives the BatchNorm-backward sums
-// (d(act) of the final conv recomputed from dpre, never stored; relu mask re-derived from y) -- added to the exact accumulators
-// of `fin`, whose last workgroup writes c1 / c2 / dgamma / dbeta (xacc.h: no finalize launch) -- AND the partial rows of the
-// final conv's weight / bias gradient (activation re-derived from y) into `partial_w`;  (2) launch_final_bn_bwd_apply: dy;
-// launch_final_wsum adds the weight-gradient rows (off the backward chain: nothing but the optimiser reads them)
+// (d(act) of the final conv recomputed from dpre, never stored; relu mask re-derived from y) into `partial` AND the partial
+// rows of the final conv's weight / bias gradient (activation re-derived from y) into `partial_w`;  (2) launch_final_bn_bwd_apply:
+// ONE finalizer launch (dW / db from partial_w, dgamma / dbeta and the two means from `partial`), then dy
 void launch_final_bwd_reduce(int dt, const float* dpre, const float* Wt, const void* y, int B, int S, int C, const float* bn,
-                             const BnFin& fin, float* partial_w, hipStream_t s);
-void launch_final_wsum(const float* partial_w, int B, int S, int C, float* dW, float* db, hipStream_t s);
-void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* Wt, const void* y, void* dy, int B, int S, int C, const float* bn,
+                             float* partial, float* partial_w, hipStream_t s);
+void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* Wt, const void* y, void* dy, int B, int S, int C, float* bn,
+                               const float* partial, const float* partial_w, float* dW, float* db, float* dgamma, float* dbeta,
                                hipStream_t s);
 
 // ---- Discriminator pieces -----------------------------------------------------------------

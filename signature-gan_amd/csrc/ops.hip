@@ -364,18 +364,19 @@ __global__ void k_bn_bwd_apply(T* __restrict__ da, const T* __restrict__ y, int6
     st4<T>(da + i * 4, f32x4{o.x, o.y, o.z, o.w});
 }
 void launch_bn_bwd(int dt, void* dav, const void* yv, int64_t R, int C, float* bn, float* partial,
-                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s, bool stats_done) {
-    // stats_done: the kernel that produced da finalized both sums itself (gconv's EPI_BN_BWD_STATS, xacc.h): apply only
+                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s, int pre_rows) {
+    // pre_rows > 0: the kernel that produced da left that many partial rows of both sums in `partial` (gconv's
+    // EPI_BN_BWD_STATS): no reduction pass over da and y
     const ColPlan pl = col_plan(R, C);
-    float* p0 = partial; float* p1 = partial + (size_t)pl.nch * C;
+    const int nch = pre_rows > 0 ? pre_rows : pl.nch;
+    float* p0 = partial; float* p1 = partial + (size_t)nch * C;
     const int64_t n4 = R * C / 4;
     SIGGAN_DT_SWITCH(dt, T, {
         T* da = (T*)dav; const T* y = (const T*)yv;
-        if (!stats_done) {
+        if (pre_rows <= 0)
             hipLaunchKernelGGL((k_colreduce<FBnBwd<T>>), dim3(pl.cbx, pl.nch), dim3(256), 0, s,
                                FBnBwd<T>{da, y, (const float4*)bn}, R, C, pl.cg, pl.rows, p0, p1);
-            launch_bn_bwd_fin(p0, p1, pl.nch, R, C, bn, dgamma, dbeta, perm_c0, s);
-        }
+        launch_bn_bwd_fin(p0, p1, nch, R, C, bn, dgamma, dbeta, perm_c0, s);
         hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(cdiv(n4, 256)), dim3(256), 0, s, da, y, n4, C / 4, (const float4*)bn);
     });
 }
@@ -643,7 +644,8 @@ __device__ __forceinline__ f4v final_dact(const float (&d)[RY + 2][3], const f4v
 template <class T, int RY>
 __global__ __launch_bounds__(256) void k_final_bwd_reduce(const float* __restrict__ dpre, const float* __restrict__ Wt,
                                                           const T* __restrict__ y, const float* __restrict__ bn,
-                                                          const BnFin fin, float* __restrict__ pw, int S, int nstrips) {
+                                                          float* __restrict__ p0, float* __restrict__ p1,
+                                                          float* __restrict__ pw, int S, int nstrips) {
     constexpr int C = 32;
     __shared__ f4v sh[2][4][8];
     __shared__ float shw[4][8][37];
@@ -729,20 +731,17 @@ __global__ __launch_bounds__(256) void k_final_bwd_reduce(const float* __restric
         shw[wave][c4][36] = sdb;
     }
     __syncthreads();
-    f4v a = {0.f, 0.f, 0.f, 0.f}, b = a;
     if (threadIdx.x < 8) {
-        a = ((sh[0][0][c4] + sh[0][1][c4]) + sh[0][2][c4]) + sh[0][3][c4];
-        b = ((sh[1][0][c4] + sh[1][1][c4]) + sh[1][2][c4]) + sh[1][3][c4];
+        const f4v a = ((sh[0][0][c4] + sh[0][1][c4]) + sh[0][2][c4]) + sh[0][3][c4];
+        const f4v b = ((sh[1][0][c4] + sh[1][1][c4]) + sh[1][2][c4]) + sh[1][3][c4];
+        *reinterpret_cast<f4v*>(p0 + (size_t)blockIdx.x * C + c4 * 4) = a;
+        *reinterpret_cast<f4v*>(p1 + (size_t)blockIdx.x * C + c4 * 4) = b;
     }
     float* out = pw + (size_t)blockIdx.x * (C * 9 + 1);
     for (int o = threadIdx.x; o < C * 9 + 1; o += 256) {
         const int g = o < C * 9 ? o / 36 : 0, j = o < C * 9 ? o % 36 : 36;     // channel c = 4*g + j/9, tap j%9
         out[o] = ((shw[0][g][j] + shw[1][g][j]) + shw[2][g][j]) + shw[3][g][j];
     }
-    // the BatchNorm-backward sums go to the block's exact accumulators; the workgroup that arrives last writes c1 / c2 / dgamma /
-    // dbeta (xacc.h): k_final_bnbwd_apply follows directly, the weight-gradient rows are added off the critical lane
-    __shared__ unsigned s_flag;
-    bn_stats_commit(fin, C, c4 * 4, threadIdx.x < 8, a, b, gridDim.x, &s_flag);
 }
 // stage 2 (after k_bn_bwd_fin): dy = scale * (dy_relu - c1 - xhat * c2), written to dy[B][S][S][C]
 template <class T>
@@ -790,6 +789,30 @@ __global__ __launch_bounds__(1024) void k_rows_sum(const float* __restrict__ par
     if (threadIdx.x >= 64 || j >= width) return;
     if (j < n0) o0[j] = s; else o1[j - n0] = s;
 }
+// Both finalizers behind k_final_bwd_reduce in ONE launch (two independent 5 us kernels on the Generator backward's
+// critical lane): blocks [0, nbw) add the partial rows of the final conv's weight / bias gradient (k_rows_sum), the block
+// behind them finalizes the last block's BatchNorm-backward sums (k_bn_bwd_fin<32>).  Same sums, same order.
+__global__ __launch_bounds__(1024) void k_final_fin(const float* __restrict__ partial_w, int nch_w, int width, float* __restrict__ dW,
+                                                    int n0, float* __restrict__ db, int nbw, const float* __restrict__ p0,
+                                                    const float* __restrict__ p1, int nch, int64_t R, int C, float* __restrict__ bn,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sh[2][16][64];
+    float s, q;
+    if ((int)blockIdx.x < nbw) {
+        gather2(partial_w, nullptr, nch_w, width, s, q, sh);
+        const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+        if (threadIdx.x >= 64 || j >= width) return;
+        if (j < n0) dW[j] = s; else db[j - n0] = s;
+        return;
+    }
+    const int bx = blockIdx.x - nbw;
+    gather2<32>(p0, p1, nch, C, s, q, sh, bx);
+    const int c = bx * 32 + (threadIdx.x & 31);
+    if (threadIdx.x >= 32 || c >= C) return;
+    dbeta[c] = s; dgamma[c] = q;                       // (perm_c0 == 0: identity)
+    const float invR = 1.0f / (float)R;
+    bn[4 * C + c] = s * invR; bn[5 * C + c] = q * invR;
+}
 // rows per strip of k_final_bwd_reduce: 4 (8-row strips need 256 registers and measured 36 vs 26 us)
 constexpr int FINAL_RY = 4;
 // two workgroups of this kernel per CU (188-204 registers): 512 of them walk the strips, each requesting strip i+1's rows while
@@ -798,21 +821,20 @@ static int final_reduce_rows(int B, int S) {
     const int n = B * (S / FINAL_RY) * (S / 32); return n < 512 ? n : 512;
 }
 void launch_final_bwd_reduce(int dt, const float* dpre, const float* Wt, const void* y, int B, int S, int C, const float* bn,
-                             const BnFin& fin, float* partial_w, hipStream_t s) {
-    (void)C;
+                             float* partial, float* partial_w, hipStream_t s) {
     const int nstrips = B * (S / FINAL_RY) * (S / 32), nch = final_reduce_rows(B, S);
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL((k_final_bwd_reduce<T, FINAL_RY>), dim3(nch), dim3(256), 0, s, dpre, Wt, (const T*)y, bn, fin,
+    float* p0 = partial; float* p1 = partial + (size_t)nch * C;
+    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL((k_final_bwd_reduce<T, FINAL_RY>), dim3(nch), dim3(256), 0, s, dpre, Wt, (const T*)y, bn, p0, p1,
                                                 partial_w, S, nstrips));
 }
-// the final conv's weight / bias gradient from k_final_bwd_reduce's partial rows (nothing on the backward chain reads it)
-void launch_final_wsum(const float* partial_w, int B, int S, int C, float* dW, float* db, hipStream_t s) {
-    const int nch = final_reduce_rows(B, S);
-    hipLaunchKernelGGL(k_rows_sum, dim3(cdiv(C * 9 + 1, 64)), dim3(1024), 0, s, partial_w, nch, C * 9 + 1, dW, C * 9, db);
-}
-void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* Wt, const void* y, void* dy, int B, int S, int C, const float* bn,
+void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* Wt, const void* y, void* dy, int B, int S, int C, float* bn,
+                               const float* partial, const float* partial_w, float* dW, float* db, float* dgamma, float* dbeta,
                                hipStream_t s) {
-    (void)C;
-    const int nstrips = B * (S / 4) * (S / 32);
+    const int nstrips = B * (S / 4) * (S / 32), nch = final_reduce_rows(B, S);
+    const float* p0 = partial; const float* p1 = partial + (size_t)nch * C;
+    const int nbw = cdiv(C * 9 + 1, 64);
+    hipLaunchKernelGGL(k_final_fin, dim3(nbw + cdiv(C, 32)), dim3(1024), 0, s, partial_w, nch, C * 9 + 1, dW, C * 9, db, nbw, p0, p1, nch,
+                       (int64_t)B * S * S, C, bn, dgamma, dbeta);
     SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_bnbwd_apply<T>, dim3(nstrips), dim3(256), 0, s, dpre, Wt, (const T*)y, bn, (T*)dy, S));
 }
 

@@ -60,6 +60,10 @@ struct DevGuard {
 
 static const float BN_MOMENTUM = 0.1f, BN_EPS = 1e-5f;   // nn.BatchNorm defaults (generator_vanilla_gan.py:58,126)
 static const int MAXL = 6;
+static const int64_t PARTIAL_FLOATS = (int64_t)2 << 20;   // each of the three reduction-partial regions (partial, partial_b, partial_c)
+#ifndef SPEC_EARLY_F32
+#define SPEC_EARLY_F32 0      // (A/B switch of a build, scratch/build_variant.sh: the G step's training forward beside the eval forward at fp32 too)
+#endif
 #define ENTER(c)                                                     \
     if (!(c)) return fail(SIGGAN_E_INVALID, "null context");          \
     DevGuard dg_((c)->cfg.device);                                    \
@@ -148,8 +152,6 @@ struct siggan_ctx {
     char* ws; size_t ws_bytes;
     // (element type dt: fc_y, g_y, g_a, g_da, d_a, d_dv and the MFMA weight packs g_up, g_dn, d_dn, d_up; fp32: the rest)
     float *z, *g_bn[MAXL + 1], *g_bne[MAXL + 1];
-    XAcc *xacc_f[MAXL + 1], *xacc_b[MAXL + 1];   // exact accumulators of the Generator blocks' BatchNorm statistics: forward [2][C], backward [2][C] (xacc.h)
-    unsigned* tickets;                           // their arrival counters: [l] forward, [MAXL + 1 + l] backward; zero between uses
     char *fc_y, *g_y[MAXL + 1], *g_a[MAXL + 1], *g_da[MAXL + 1];
     char *g_ae[MAXL + 1];     // 16-bit contexts: activations of the EVAL-mode Generator forward (it runs beside the training forward)
     float *img, *dpre;
@@ -301,18 +303,11 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
             const int64_t H = 4 << l, n = Bm * H * H * c->gC[l];
             if (l == 0) c->g_y[0] = c->fc_y; else carve_t(&c->g_y[l], n);
             carve_t(&c->g_a[l], n);
-            if (c->dt != DT_F32) carve_t(&c->g_ae[l], n); else if (pass == 1) c->g_ae[l] = c->g_a[l];
+            if (c->dt != DT_F32 || SPEC_EARLY_F32) carve_t(&c->g_ae[l], n); else if (pass == 1) c->g_ae[l] = c->g_a[l];
             carve_t(&c->g_da[l], n);
             carve(&c->g_bn[l], 6 * (int64_t)(l == 0 ? c->F : c->gC[l]));
             carve(&c->g_bne[l], 4 * (int64_t)(l == 0 ? c->F : c->gC[l]));   // eval-mode [scale|shift|mean|rstd]
-            if (l >= 1) {
-                float *xf = nullptr, *xb = nullptr;
-                carve(&xf, 2 * (int64_t)c->gC[l] * (int64_t)(sizeof(XAcc) / sizeof(float)));
-                carve(&xb, 2 * (int64_t)c->gC[l] * (int64_t)(sizeof(XAcc) / sizeof(float)));
-                if (pass == 1) { c->xacc_f[l] = (XAcc*)xf; c->xacc_b[l] = (XAcc*)xb; }
-            }
         }
-        { float* tk = nullptr; carve(&tk, 64); if (pass == 1) c->tickets = (unsigned*)tk; }
         if (pass == 1) c->g_y[0] = c->fc_y;
         carve(&c->img, Bm * c->S * c->S);
         carve(&c->dpre, Bm * c->S * c->S);
@@ -337,10 +332,10 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->slab_k, c->slab_k_floats);
         if (c->dt != DT_F32) carve(&c->slab_b, c->slab_floats); else if (pass == 1) c->slab_b = c->slab;
         carve(&c->slab_k2, c->slab_k_floats);
-        if (c->dt != DT_F32) carve(&c->slab_k3, c->slab_k_floats); else if (pass == 1) c->slab_k3 = c->slab_k2;
-        carve(&c->partial, (int64_t)2 << 20);
-        carve(&c->partial_b, (int64_t)2 << 20);
-        carve(&c->partial_c, (int64_t)2 << 20);
+        if (c->dt != DT_F32 || SPEC_EARLY_F32) carve(&c->slab_k3, c->slab_k_floats); else if (pass == 1) c->slab_k3 = c->slab_k2;
+        carve(&c->partial, PARTIAL_FLOATS);
+        carve(&c->partial_b, PARTIAL_FLOATS);
+        carve(&c->partial_c, PARTIAL_FLOATS);
         carve(&c->z_g, Bm * c->latent);
         carve(&c->img_g, Bm * c->S * c->S);
         carve(&c->real_stage, Bm * c->S * c->S);
@@ -652,19 +647,6 @@ static GConvArgs gconv_args(siggan_ctx* c) {
     return a;
 }
 
-// What the last workgroup of a statistics epilogue finalizes for Generator block l (xacc.h): kind 1 = the batch statistics of
-// its pre-BatchNorm tensor y[l] (table + running statistics), kind 2 = the BatchNorm-backward sums of d(relu output) of block l.
-static BnFin bn_fin(siggan_ctx* c, int l, int kind, int64_t R) {
-    BnFin f; memset(&f, 0, sizeof f);
-    f.kind = kind; f.acc = kind == 1 ? c->xacc_f[l] : c->xacc_b[l]; f.ticket = c->tickets + (kind == 1 ? l : MAXL + 1 + l);
-    f.bn = c->g_bn[l]; f.R = R; f.momentum = BN_MOMENTUM; f.eps = BN_EPS;
-    f.gamma = GP(c, gi_bn_w(l)); f.beta = GP(c, gi_bn_b(l));
-    f.rmean = c->st.g_bn_running_mean + c->g_bn_off[l]; f.rvar = c->st.g_bn_running_var + c->g_bn_off[l];
-    f.batches = c->st.g_bn_batches + l;
-    f.dgamma = c->st.g_grads ? GG(c, gi_bn_w(l)) : nullptr; f.dbeta = c->st.g_grads ? GG(c, gi_bn_b(l)) : nullptr;
-    return f;
-}
-
 // Generator.forward (generator_vanilla_gan.py:189-209).  training: BN batch stats (+ running
 // update) and raw pre-BN outputs kept for the backward pass; eval: BN folded into the epilogue.
 // z == nullptr: the latent batch is drawn inside the fc kernel from RNG stream rng_sid and left in z_out.
@@ -695,16 +677,14 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
         const int C = Co;
         const int64_t off = c->g_bn_off[l];
         if (training) {
-            // the block's batch statistics ride in the GEMM's epilogue and its last workgroup writes the table and the running
-            // statistics (EPI_BN_FWD_STATS, xacc.h): no reduction pass over y, no finalize launch
+            a.out = c->g_y[l]; a.epi = EPI_RAW;
+            launch_gconv(a, s);
             const int64_t R = (int64_t)B * 4 * Hi * Hi;
-            a.out = c->g_y[l]; a.epi = EPI_BN_FWD_STATS; a.fin = bn_fin(c, l, 1, R);
-            if (!launch_gconv(a, s))       // (every tile configuration of this model takes the epilogue; the generic pass stays for any that does not)
-                launch_bn_train_stats(c->dt, c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
-                                      c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
-                                      BN_MOMENTUM, BN_EPS, s);
             // the LAST block's activation has two readers, the final conv here and its weight gradient in the backward
             // pass: both re-derive it from y and this table, so it is never written (33.5 MB each way at batch 64)
+            launch_bn_train_stats(c->dt, c->g_y[l], R, C, GP(c, gi_bn_w(l)), GP(c, gi_bn_b(l)), c->st.g_bn_running_mean + off,
+                                  c->st.g_bn_running_var + off, c->st.g_bn_batches + l, c->g_bn[l], partial, 0,
+                                  BN_MOMENTUM, BN_EPS, s);
             if (l < c->Lg) launch_bn_relu(c->dt, c->g_y[l], A[l], R, C, c->g_bn[l], s);
         } else {
             a.out = A[l]; a.epi = EPI_AFFINE_RELU; a.scale = c->g_bne[l]; a.shift = c->g_bne[l] + C;
@@ -849,19 +829,18 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
 // BatchNorm backward and the input-gradient chain; lane a: the weight gradients.
 static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     const int Lg = c->Lg, S = c->S;
-    int stats_done = 0;            // block l's BatchNorm-backward sums were finalized by the input-gradient GEMM of block l+1
+    int pre_rows = 0;              // partial rows of block l's BatchNorm-backward sums left by the input-gradient GEMM of block l+1
     for (int l = Lg; l >= 1; --l) {
         const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
         const int64_t R = (int64_t)B * Ho * Ho;
         if (l == Lg) {   // final conv's input-gradient folded into this block's BatchNorm backward; its weight gradient rides in
-                         // the same pass over y; the sums are finalized by that launch's last workgroup (xacc.h)
-            launch_final_bwd_reduce(c->dt, c->dpre, c->wfin_t, c->g_y[l], B, S, Co, c->g_bn[l], bn_fin(c, l, 2, R), c->partial_b, L.m);
-            launch_final_bn_bwd_apply(c->dt, c->dpre, c->wfin_t, c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], L.m);
+                         // the same pass over y and its row sums stay on this lane (a 5 us kernel does not pay for a fork + join)
+            launch_final_bwd_reduce(c->dt, c->dpre, c->wfin_t, c->g_y[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b, L.m);
+            launch_final_bn_bwd_apply(c->dt, c->dpre, c->wfin_t, c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b,
+                                      GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
         } else
-            launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m, stats_done != 0);
+            launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m, pre_rows);
         L.fork(L.a);                                       // dy[l] is complete on m here
-        if (l == Lg)     // the final conv's weight / bias gradient from the rows k_final_bwd_reduce left: nothing on this chain reads it
-            launch_final_wsum(c->partial_b, B, S, Co, GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), L.a);
         // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
         // (one fork per block; per two blocks measured the same, weight gradients on the main lane 2.5 % slower: DESIGN 4)
         WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
@@ -875,9 +854,9 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
         a.B = B; a.Hi = Ho; a.Wi = Ho; a.Ci = Co; a.Co = Ci;
         a.lgHr = ilog2i(Hi); a.lgWr = a.lgHr; a.Ho = Hi; a.Wo = Hi; a.form = 0; a.M = B * Hi * Hi; a.epi = EPI_RAW;
         if (l >= 2) {              // its output is d(relu output) of block l-1: that block's BatchNorm-backward sums ride in the epilogue
-            a.epi = EPI_BN_BWD_STATS; a.aref = c->g_y[l - 1]; a.bnp = c->g_bn[l - 1]; a.fin = bn_fin(c, l - 1, 2, (int64_t)B * Hi * Hi);
+            a.epi = EPI_BN_BWD_STATS; a.aref = c->g_y[l - 1]; a.bnp = c->g_bn[l - 1]; a.stat0 = c->partial; a.stat_cap = PARTIAL_FLOATS;
         }
-        stats_done = launch_gconv(a, L.m);
+        pre_rows = launch_gconv(a, L.m);
     }
     if (!(c->fc_fused && launch_fc_bwd_fused(c->dt, c->g_da[0], c->fc_y, z, c->g_bn[0], GG(c, gi_fc_w()), GG(c, gi_fc_b()),
                                              GG(c, gi_bn0_w()), GG(c, gi_bn0_b()), B, c->latent, c->gC[0], L.m))) {
@@ -988,7 +967,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // forward's activations in buffers of their own: bf16 batch 64 0.747 -> 0.723 ms.  fp32 keeps it behind D(fake) (below):
     // there the early start measured 0.7 % slower -- its BatchNorm / fc kernels take matrix-pipe time from the eval forward,
     // which is on the step's critical lane.
-    const bool spec_early = spec_fwd && c->dt != DT_F32;
+    const bool spec_early = spec_fwd && (c->dt != DT_F32 || SPEC_EARLY_F32);
     hipEvent_t e_early = nullptr;
     if (spec_early) { e_early = L.next(); L.record(e_early, L.m); }
     if (k.variant == SIGGAN_STEP_ABLATION) {

@@ -376,7 +376,8 @@ def test_three_step_sequence(size, latent, batch):
         nflips += len(flips_vs_census(f, f"seq3/g{s}", hs))
         for name, d_, g_ in (("A", dm, gm), ("B", bm, bg), ("C", cm, cg)):
             rows[name].append([d_[k] for k in dk] + [g_[k] for k in gk])
-    A, B, Cm, G = (np.array(rows[k], np.float64) for k in "ABC") + (np.asarray(f["seq3/metrics"], np.float64),)
+    A, B, Cm = (np.array(rows[k], np.float64) for k in "ABC")
+    G = np.asarray(f["seq3/metrics"], np.float64)
     assert_close(Cm, G, 1e-4, 1e-5, "3-step metrics: oracle(reference's decisions) vs the reference")
     row = {"flips_vs_reference": nflips, "hip_vs_oracle_with_hip_signs": worst,
            "metrics_vs_reference": float(np.abs(A - G).max()), "predicted_by_the_flips": float(np.abs(B - Cm).max())}
