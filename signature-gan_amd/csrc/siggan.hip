@@ -61,6 +61,9 @@ struct DevGuard {
 static const float BN_MOMENTUM = 0.1f, BN_EPS = 1e-5f;   // nn.BatchNorm defaults (generator_vanilla_gan.py:58,126)
 static const int MAXL = 6;
 static const int64_t PARTIAL_FLOATS = (int64_t)2 << 20;   // each of the three reduction-partial regions (partial, partial_b, partial_c)
+#ifndef EV_FLAGS
+#define EV_FLAGS hipEventDisableTiming
+#endif
 #ifndef SPEC_EARLY_F32
 #define SPEC_EARLY_F32 0      // (A/B switch of a build, scratch/build_variant.sh: the G step's training forward beside the eval forward at fp32 too)
 #endif
@@ -377,8 +380,8 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->s_b, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->s_c, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->s_n, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_gfwd, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_dreal, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_gfwd, EV_FLAGS));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_dreal, EV_FLAGS));
     HIPCHK(hipEventCreateWithFlags(&c->ev_ar, hipEventDisableTiming));
     c->early_ar = false;
     c->staged_B = c->dreal_B = 0; c->staged_src = nullptr; c->dreal_joined = c->dreal_noise2 = c->gfwd_joined = false;
@@ -388,7 +391,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     c->zg_stash = 0;
     c->ga_last_B = 0; c->g_r0 = 0;
     c->adam_t_known[0] = c->adam_t_known[1] = false;
-    for (int i = 0; i < siggan_ctx::NEV; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    for (int i = 0; i < siggan_ctx::NEV; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], EV_FLAGS));
     for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_bridge[i], hipEventDisableTiming));
     *out = c;
     return SIGGAN_OK;
