@@ -157,12 +157,6 @@ int siggan_rng_state(siggan_ctx *ctx, uint64_t *seed, uint64_t *offset);
  * the weight-gradient / reduction kernels on side streams beside the input-gradient chain. */
 #define SIGGAN_MODE_GRAPH 1
 #define SIGGAN_MODE_OVERLAP 2
-/* SIGGAN_MODE_DEFER_D_TAIL (with SIGGAN_MODE_OVERLAP, eager): inside a pipelined step (siggan_step_begin) siggan_d_apply may
- * leave the optimiser update of the Discriminator's last block + classifier (and their weight re-packs) running on a lane of
- * the library's own; the siggan_g_grads that must follow waits for it where it first needs those weights, every other entry
- * point waits at once.  A caller that sets it must not touch the Discriminator's parameter / gradient / moment arenas between
- * those two calls other than through this library (results are bit-identical either way). */
-#define SIGGAN_MODE_DEFER_D_TAIL 4
 int siggan_set_mode(siggan_ctx *ctx, int32_t mode);
 
 /* Which of the reference's two G+D iterations the step calls implement (default SIGGAN_STEP_TRAINER):

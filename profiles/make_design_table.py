@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Print the DESIGN.md section-5 table from the tracked bench lines (profiles/r03_bench_*.json), so the document quotes the files."""
+"""Print the DESIGN.md section-5 table from the tracked bench lines (profiles/r04_bench_*.json), so the document quotes the files."""
 import json
 import os
 
@@ -17,8 +17,8 @@ rows = [("**configs[1]** 64×64 z = 100 batch 64 fp32 (the bench line)", "defaul
 print("| workload | `value` | ms/step (median; p10–p90) | whole-step fraction of MFMA peak | dominant kernel | file |")
 print("|---|---|---|---|---|---|")
 for label, tag in rows:
-    d = json.load(open(os.path.join(HERE, f"r03_bench_{tag}.json")))
+    d = json.load(open(os.path.join(HERE, f"r04_bench_{tag}.json")))
     t, r = d.get("timing", {}), d.get("roofline")
     kern = "—" if not r else f"`{r['kernel']}` {r['achieved']:.1f} TFLOP/s = {r['frac']:.3f}, {r['avg_launch_us']:.1f} µs × {r['launches_per_step']:.0f}/step"
     print(f"| {label} | {d['value'] / 1e3:.1f} k images/s | {d['ms_per_step']:.3f} ({t.get('ms_per_step_p10', 0):.3f}–{t.get('ms_per_step_p90', 0):.3f}) | "
-          f"{d['frac_of_mfma_peak_whole_step']:.3f} | {kern} | `r03_bench_{tag}.json` |")
+          f"{d['frac_of_mfma_peak_whole_step']:.3f} | {kern} | `r04_bench_{tag}.json` |")

@@ -76,9 +76,9 @@ __global__ __launch_bounds__(256) void k_gemm3(const float* __restrict__ A, cons
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(&sB[buf][p][o]) = rb[p];
     };
-    f32x16 acc0, acc1;
+    f32x16 acc0, acc1, acc2;      // three independent chains (hi.hi | hi.mid + mid.hi | the three small products): no MFMA waits for the one before it
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
     load_tile(); store_tile(0);
     if (nk > 1) load_tile();
     __syncthreads();
@@ -93,16 +93,14 @@ __global__ __launch_bounds__(256) void k_gemm3(const float* __restrict__ A, cons
                 fa[p] = *reinterpret_cast<const bf16x8*>(&sA[buf][p][oa + 16 * s]);
                 fb[p] = *reinterpret_cast<const bf16x8*>(&sB[buf][p][ob + 16 * s]);
             }
-            if (NT >= 6) {
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc1, 0, 0, 0);
-            }
-            if (NT >= 3) {
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc1, 0, 0, 0);
-            }
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc0, 0, 0, 0);
+            if (NT >= 3) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc1, 0, 0, 0);
+            if (NT >= 6) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc2, 0, 0, 0);
+            if (NT >= 3) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc1, 0, 0, 0);
+            if (NT >= 6) {
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc2, 0, 0, 0);
+            }
             if (s == 0 && kt + 1 < nk) store_tile(buf ^ 1);
             if (s == 1 && kt + 2 < nk) load_tile();
         }
@@ -111,7 +109,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const float* __restrict__ A, cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n = n0 + wn * 32 + li;
-        C[(size_t)m * N + n] = acc0[r] + acc1[r];
+        C[(size_t)m * N + n] = acc0[r] + (acc1[r] + acc2[r]);
     }
 }
 

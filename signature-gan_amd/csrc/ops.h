@@ -185,8 +185,7 @@ __host__ __device__ inline double pow_step(double b, double t) {
 // writes steps[0..ntensors) = t, ticks the RNG epoch and stores the pre-clip norm.  Same update arithmetic as launch_adam.
 void launch_adam_fused(float* p, float* g, float* m, float* v, int64_t n, DevState* st, float* steps, int ntensors, double t,
                        double lr, double beta1, double beta2, double eps, float grad_scale, float clip_max_norm,
-                       float* metric_norm, const float* sumsq_partial, hipStream_t s, float* metric_skipped = nullptr,
-                       bool block0 = true);   // block0 = false: a further range of the same update (p .. v point at the range)
+                       float* metric_norm, const float* sumsq_partial, hipStream_t s, float* metric_skipped = nullptr);
 void launch_adam(float* p, float* g, float* m, float* v, int64_t n, const DevState* st, double beta1,
                  double beta2, double eps, int write_back_grad, hipStream_t s);
 

@@ -1391,7 +1391,6 @@ struct AdamHost {          // scalars of a fused update, formed on the host (FUS
     float* steps;
     float* metric_norm;
     float* metric_skipped;        // the step's "update skipped" flag: a fused update never skips, it writes 0 (include/siggan.h)
-    int block0;                   // this launch does block 0's bookkeeping (step tensors, RNG epoch, norm): exactly one launch of a split update does
     const float* sumsq_partial;   // k_sumsq's block partials (clip): every block's wave 0 adds them itself
 };
 template <bool FUSED>
@@ -1415,7 +1414,7 @@ __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __
             norm = sqrtf(s_ssq) * h.grad_scale;
             mul = h.grad_scale * fminf(h.clip_max_norm / (norm + 1e-6f), 1.0f);
         }
-        if (blockIdx.x == 0 && h.block0) {                             // what k_adam_prepare does besides the scalars
+        if (blockIdx.x == 0) {                                         // what k_adam_prepare does besides the scalars
             for (int i = threadIdx.x; i < h.ntensors; i += 256) h.steps[i] = h.t;
             if (threadIdx.x == 0) {
                 st->rng_ctr += 1;                                      // every optimiser update starts a new RNG epoch
@@ -1455,14 +1454,14 @@ __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __
 }
 void launch_adam_fused(float* p, float* g, float* m, float* v, int64_t n, DevState* st, float* steps, int ntensors, double t,
                        double lr, double beta1, double beta2, double eps, float grad_scale, float clip_max_norm,
-                       float* metric_norm, const float* sumsq_partial, hipStream_t s, float* metric_skipped, bool block0) {
+                       float* metric_norm, const float* sumsq_partial, hipStream_t s, float* metric_skipped) {
     const int64_t n4 = n / 4;
     const int tail = (int)(n - n4 * 4);
     AdamHost h;
     h.step_size = (float)(lr / (1.0 - pow_step(beta1, t)));            // torch.optim.Adam: lr / (1 - beta1**step), in double
     h.bc2_sqrt = (float)sqrt(1.0 - pow_step(beta2, t));
     h.grad_scale = grad_scale; h.clip_max_norm = clip_max_norm; h.t = (float)t; h.ntensors = ntensors; h.steps = steps;
-    h.metric_norm = metric_norm; h.metric_skipped = metric_skipped; h.sumsq_partial = sumsq_partial; h.block0 = block0 ? 1 : 0;
+    h.metric_norm = metric_norm; h.metric_skipped = metric_skipped; h.sumsq_partial = sumsq_partial;
     const int wb = (clip_max_norm > 0.f || grad_scale != 1.0f) ? 1 : 0;
     hipLaunchKernelGGL(k_adam<true>, dim3(cdiv(n4 + tail, 256)), dim3(256), 0, s, (float4*)p, (float4*)g, (float4*)m, (float4*)v,
                        n4, p + n4 * 4, g + n4 * 4, m + n4 * 4, v + n4 * 4, tail, st, (float)(1.0 - beta1), (float)beta2,

@@ -70,13 +70,6 @@ static const int64_t PARTIAL_FLOATS = (int64_t)2 << 20;   // each of the three r
 #ifndef EV_FLAGS
 #define EV_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
 #endif
-#ifndef DEFER_TAIL_DEFAULT
-#define DEFER_TAIL_DEFAULT 0
-#endif
-#define DEFER_TAIL(c) (DEFER_TAIL_DEFAULT || ((c)->mode & SIGGAN_MODE_DEFER_D_TAIL) != 0)
-#ifndef SPEC_EARLY_F32
-#define SPEC_EARLY_F32 0      // (A/B switch of a build, scratch/build_variant.sh: the G step's training forward beside the eval forward at fp32 too)
-#endif
 #define ENTER(c)                                                     \
     if (!(c)) return fail(SIGGAN_E_INVALID, "null context");          \
     DevGuard dg_((c)->cfg.device);                                    \
@@ -127,14 +120,14 @@ static Rccl* rccl() {
     } while (0)
 
 struct PhaseKey {
-    int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg, pre_real, variant, coll, split_tail;   // coll: an apply call follows (collectives may start early)
+    int phase, B, has_z, has_masks, g_dirty, d_dirty, spec_g, has_zg, pre_real, variant, coll;   // coll: an apply call follows (collectives may start early)
     float* mt;   // where the phase writes its metrics (caller's buffer, or the workspace one)
     double lr, beta1, beta2, eps;
     double fused_t;   // > 0: the step count (after the increment) of a one-launch optimiser update; 0: k_adam_prepare path
     float ls, clip, gs;
     bool operator==(const PhaseKey& o) const {
         return phase == o.phase && B == o.B && has_z == o.has_z && has_masks == o.has_masks && g_dirty == o.g_dirty &&
-               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && pre_real == o.pre_real && variant == o.variant && coll == o.coll && split_tail == o.split_tail && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
+               d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && pre_real == o.pre_real && variant == o.variant && coll == o.coll && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
                clip == o.clip && gs == o.gs && fused_t == o.fused_t;
     }
 };
@@ -188,13 +181,6 @@ struct siggan_ctx {
     hipStream_t s_m, s_a, s_b, s_c, s_n;      // s_n: the lane of an all-reduce issued while the backward pass is still running
     hipEvent_t ev_gfwd, ev_dreal, ev_ar, ev_sys[2];
     bool early_ar;       // the last D block's weight gradient is already being all-reduced on s_n (ev_ar marks its end)
-    // SIGGAN_MODE_DEFER_D_TAIL: in a pipelined step the Discriminator update is split at the last block -- the head of the arena
-    // (blocks 1 .. Ld-1, 24 % of it) is updated and re-packed on the caller's stream, the tail (last block + classifier: the bulk
-    // of the bytes, needed only by the FOURTH GEMM of the next Discriminator pass) on lane s_n; siggan_g_grads waits for ev_dtail
-    // where that GEMM is enqueued, every other entry point at once (settle)
-    hipEvent_t ev_dtail, ev_join_a, ev_join_b;   // ev_join_*: the events of the D backward's two joins (its gradients are complete behind them)
-    bool d_tail_pending; // the tail's update / packs are still running on s_n
-    bool d_tail_clean;   // the tail's packs already follow the updated weights (repack skips them)
     bool dreal_orphan;   // a D(real) forward enqueued on lane c was abandoned: the next enqueue waits for ev_dreal first
     hipError_t lane_err; // first failed event record / wait of a fork or join (checked after every phase)
     // data-parallel communicator (siggan_comm_init): world 1 = none
@@ -323,7 +309,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
             const int64_t H = 4 << l, n = Bm * H * H * c->gC[l];
             if (l == 0) c->g_y[0] = c->fc_y; else carve_t(&c->g_y[l], n);
             carve_t(&c->g_a[l], n);
-            if (c->dt != DT_F32 || SPEC_EARLY_F32) carve_t(&c->g_ae[l], n); else if (pass == 1) c->g_ae[l] = c->g_a[l];
+            if (c->dt != DT_F32) carve_t(&c->g_ae[l], n); else if (pass == 1) c->g_ae[l] = c->g_a[l];
             carve_t(&c->g_da[l], n);
             carve(&c->g_bn[l], 6 * (int64_t)(l == 0 ? c->F : c->gC[l]));
             carve(&c->g_bne[l], 4 * (int64_t)(l == 0 ? c->F : c->gC[l]));   // eval-mode [scale|shift|mean|rstd]
@@ -352,7 +338,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->slab_k, c->slab_k_floats);
         if (c->dt != DT_F32) carve(&c->slab_b, c->slab_floats); else if (pass == 1) c->slab_b = c->slab;
         carve(&c->slab_k2, c->slab_k_floats);
-        if (c->dt != DT_F32 || SPEC_EARLY_F32) carve(&c->slab_k3, c->slab_k_floats); else if (pass == 1) c->slab_k3 = c->slab_k2;
+        if (c->dt != DT_F32) carve(&c->slab_k3, c->slab_k_floats); else if (pass == 1) c->slab_k3 = c->slab_k2;
         carve(&c->partial, PARTIAL_FLOATS);
         carve(&c->partial_b, PARTIAL_FLOATS);
         carve(&c->partial_c, PARTIAL_FLOATS);
@@ -401,8 +387,6 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_dreal, EV_FLAGS));
     HIPCHK(hipEventCreateWithFlags(&c->ev_ar, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_sys[i], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_dtail, EV_FLAGS));
-    c->ev_join_a = c->ev_join_b = nullptr; c->d_tail_pending = c->d_tail_clean = false;
     c->early_ar = false;
     c->staged_B = c->dreal_B = 0; c->staged_src = nullptr; c->dreal_joined = c->dreal_noise2 = c->gfwd_joined = false;
     c->dreal_orphan = false; c->lane_err = hipSuccess;
@@ -433,7 +417,6 @@ extern "C" int siggan_destroy(siggan_ctx* c) {
     if (c->s_c) (void)hipStreamDestroy(c->s_c);
     if (c->s_n) (void)hipStreamDestroy(c->s_n);
     if (c->ev_ar) (void)hipEventDestroy(c->ev_ar);
-    if (c->ev_dtail) (void)hipEventDestroy(c->ev_dtail);
     for (int i = 0; i < 2; ++i) if (c->ev_sys[i]) (void)hipEventDestroy(c->ev_sys[i]);
     if (c->ev_gfwd) (void)hipEventDestroy(c->ev_gfwd);
     if (c->ev_dreal) (void)hipEventDestroy(c->ev_dreal);
@@ -470,11 +453,7 @@ extern "C" int64_t siggan_workspace_bytes(const siggan_ctx* c) { return c ? (int
 static void drop_dreal(siggan_ctx* c) {
     if (c->dreal_B) { c->dreal_orphan = true; c->dreal_B = 0; }
 }
-static int settle(siggan_ctx* c, hipStream_t s, bool keep_dtail = false) {
-    if (c->d_tail_pending && !keep_dtail) {          // (siggan_g_grads waits where the tail is first needed instead)
-        HIPCHK(hipStreamWaitEvent(s, c->ev_dtail, 0));
-        c->d_tail_pending = false;
-    }
+static int settle(siggan_ctx* c, hipStream_t s) {
     if (c->dreal_orphan) {
         HIPCHK(hipStreamWaitEvent(s, c->ev_dreal, 0));
         c->dreal_orphan = false;
@@ -514,7 +493,6 @@ extern "C" int siggan_bind(siggan_ctx* c, const siggan_storage* st) {
     c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0; c->staged_B = 0;
     c->adam_t_known[0] = c->adam_t_known[1] = false;
     c->early_ar = false;               // (an early all-reduce whose apply never ran is abandoned with the gradients it covered)
-    c->d_tail_clean = false; c->ev_join_a = c->ev_join_b = nullptr;
     drop_dreal(c);
     return SIGGAN_OK;
 }
@@ -522,7 +500,7 @@ extern "C" int siggan_params_changed(siggan_ctx* c) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     c->g_dirty = c->d_dirty = true;
     c->adam_t_known[0] = c->adam_t_known[1] = false;      // (optimizer.load_state_dict writes the step tensors)
-    c->early_ar = false; c->d_tail_clean = false;
+    c->early_ar = false;
     drop_dreal(c);                     // a D(real) forward started ahead of time used the old weights
     return SIGGAN_OK;
 }
@@ -567,9 +545,8 @@ static int check_call(siggan_ctx* c, int batch, bool need_bound = true) {
 // (for G) the BatchNorm eval-mode scale/shift tables.  sg / sd: the lanes the two launches go to.
 // conv1_x != nullptr (G step, no spectral norm): the D table's launch also runs the first-block forward of conv1_B images at
 // conv1_x into workspace rows [conv1_r0, ...) -- it reads the raw block-1 weights, not a pack (launch_prepare_conv1)
-// d_part: 0 = every Discriminator pack (minus the tail's when d_tail_clean), 2 = the tail's only (last block + classifier)
 static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, bool do_d, int sn_slot = 0, const float* conv1_x = nullptr,
-                   int conv1_r0 = 0, int conv1_B = 0, int d_part = 0) {
+                   int conv1_r0 = 0, int conv1_B = 0) {
     if (do_g) {
         PrepTable t; t.njobs = 0; t.overflow = 0;
         PrepJob j; memset(&j, 0, sizeof j);
@@ -603,9 +580,7 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
     if (do_d) {
         PrepTable t; t.njobs = 0; t.overflow = 0;
         PrepJob j;
-        const bool skip_tail = d_part == 0 && c->d_tail_clean && !c->sn, only_tail = d_part == 2;
         for (int l = 2; l <= c->Ld; ++l) {
-            if ((l == c->Ld && skip_tail) || (l != c->Ld && only_tail)) continue;
             const long long n = (long long)c->dC[l - 1] * c->dC[l] * 16;
             memset(&j, 0, sizeof j);
             j.src = DP(c, di_w(l)); j.dt = c->dt;                      // (Cout, Cin, 4, 4)
@@ -615,24 +590,20 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
             j.type = PREP_PACK_UP; j.I = c->dC[l]; j.O = c->dC[l - 1]; j.dst = (float*)c->d_up[l];    // input-gradient: contract Cout
             prep_add(t, j, n);
         }
-        if (!skip_tail) {
         memset(&j, 0, sizeof j);
         j.type = PREP_CLS; j.O = c->dC[c->Ld]; j.src = DP(c, di_cls_w(c)); j.dst = c->wcp;
         if (c->sn) j.mul = c->sn_sig + (sn_slot * 2 + 1) * SnTable::MAXS + c->Ld;
         prep_add(t, j, (long long)c->dC[c->Ld] * 16);
-        }
         if (c->sn) {                                                   // block 1 is not an MFMA kernel: an fp32 scaled copy
             memset(&j, 0, sizeof j);
             j.type = PREP_SCALE; j.O = c->dC[1] * 16; j.src = DP(c, di_w(1)); j.dst = c->d_w1s;
             j.mul = c->sn_sig + (sn_slot * 2 + 1) * SnTable::MAXS;
             prep_add(t, j, j.O);
         }
-        if (!only_tail) {
         memset(&j, 0, sizeof j);                                       // block 1 as [tap][co] for its input-gradient kernel
         j.type = PREP_TAPS; j.I = 16; j.O = c->dC[1]; j.src = DP(c, di_w(1)); j.dst = c->d_w1t;
         if (c->sn) j.mul = c->sn_sig + (sn_slot * 2 + 1) * SnTable::MAXS;
         prep_add(t, j, j.O * 16);
-        }
         bool ok;
         if (conv1_x && !c->sn) {
             const int64_t H = c->S >> 1;
@@ -669,11 +640,10 @@ struct Lanes {
         hipEvent_t e = next();
         note(hipEventRecord(e, m)); note(hipStreamWaitEvent(to, e, 0));
     }
-    hipEvent_t join(hipStream_t from) {  // m waits for everything enqueued on `from`; returns the event (nullptr: same lane)
-        if (from == m) return nullptr;
+    void join(hipStream_t from) {        // m waits for everything enqueued on `from`
+        if (from == m) return;
         hipEvent_t e = next();
         note(hipEventRecord(e, from)); note(hipStreamWaitEvent(m, e, 0));
-        return e;
     }
     // a failed record / wait would silently drop an ordering edge: remember the first one, run_phase reports it
     void note(hipError_t e) { if (e != hipSuccess && c->lane_err == hipSuccess) c->lane_err = e; }
@@ -742,9 +712,8 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
 // Discriminator conv blocks + classifier logits for nB images written to workspace rows
 // [r0, r0 + nB) (the D step runs D(real) into rows [0,B) on a side lane while the Generator
 // produces the fakes, then D(fake) into rows [B,2B); backward treats the 2B rows as one batch).
-// wait_last: an event the LAST block's launch must be behind (the tail of a split Discriminator update, ev_dtail)
 static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool dropout, hipStream_t s, float* slab_k,
-                           bool fuse_cls = false, bool conv1_done = false, hipEvent_t wait_last = nullptr) {
+                           bool fuse_cls = false, bool conv1_done = false) {
     const float slope = c->cfg.leaky_slope;
     auto act = [&](int l) { const int64_t H = c->S >> l; return c->d_a[l] + (size_t)((int64_t)r0 * H * H * c->dC[l]) * c->es; };
     auto nz = [&](int l) { return dropout ? c->d_noise[l] + (int64_t)r0 * c->dC[l] : nullptr; };
@@ -762,7 +731,6 @@ static void d_forward_rows(siggan_ctx* c, const float* x, int r0, int nB, bool d
         // the classifier's dot product rides there as P partials per image and k_cls_fwd is not launched
         const int P_max = c->dC[c->Ld] * 16 / 1024;
         if (l == c->Ld && fuse_cls && P_max >= 1 && P_max <= 16) { a.cls_w = c->wcp; a.cls_part = c->lparts + (size_t)r0 * P_max; }
-        if (l == c->Ld && wait_last && hipStreamWaitEvent(s, wait_last, 0) != hipSuccess) c->lane_err = hipErrorInvalidValue;
         const int P = launch_gconv(a, s);
         if (l == c->Ld) c->lP[r0 == 0 ? 0 : 1] = a.cls_w ? P : 0;
     }
@@ -856,13 +824,13 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
         }
     }
     if (want_wgrad && c->dt != DT_F32 && garena == nullptr) {
-        c->ev_join_a = L.join(L.a);
-        c->ev_join_b = L.join(L.b);
+        L.join(L.a);
+        L.join(L.b);
     } else if (want_wgrad) {
         L.fork(L.b);
         launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
-        hipEvent_t ja = L.join(L.a), jb = L.join(L.b);
-        if (garena == nullptr) { c->ev_join_a = ja; c->ev_join_b = jb; }
+        L.join(L.a);
+        L.join(L.b);
     }
     if (want_dimage)
         launch_conv1_dgrad_tanh(c->dt, dvp(1), c->d_w1t, x0, c->dpre, Bd, c->S, c->dC[1], L.m);
@@ -1008,9 +976,9 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // siggan_step_begin: the G step's training forward depends on nothing the D step changes.  16-bit contexts (every kernel
     // is a few microseconds: the step is a chain of launch latencies) start it HERE, beside the eval forward, with the eval
     // forward's activations in buffers of their own: bf16 batch 64 0.747 -> 0.723 ms.  fp32 keeps it behind D(fake) (below):
-    // there the early start measured 0.7 % slower -- its BatchNorm / fc kernels take matrix-pipe time from the eval forward,
-    // which is on the step's critical lane.
-    const bool spec_early = spec_fwd && (c->dt != DT_F32 || SPEC_EARLY_F32);
+    // there the early start measured 0.7 % slower (round 3) / 0.1 % faster with fence-free events (round 4: noise) -- its
+    // BatchNorm / fc kernels take matrix-pipe time from the eval forward, which is on the step's critical lane.
+    const bool spec_early = spec_fwd && c->dt != DT_F32;
     hipEvent_t e_early = nullptr;
     if (spec_early) { e_early = L.next(); L.record(e_early, L.m); }
     if (k.variant == SIGGAN_STEP_ABLATION) {
@@ -1094,19 +1062,16 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // backward: +1.3 % (round 3).  (ablation step: its dropout tables are drawn for rows [0, B); spectral norm: no staging)
     const int r0g = (!abl && !c->sn) ? B : 0;
     c->g_r0 = r0g;
-    // a split Discriminator update (phase_apply): its tail may still be running on s_n -- each pass waits where its last block starts
-    hipEvent_t const wl = c->d_tail_pending ? c->ev_dtail : nullptr;
-    c->d_tail_pending = false;
     const bool real_early = k.pre_real && r0g != 0;
     if (real_early) {
         const bool drop = c->cfg.dropout > 0.f;
         L.fork(c->s_c);                                               // D's packs are complete on m here
         if (drop) make_noise(c, nullptr, B, 0, 2, c->s_c, 1);       // the D(fake) pass' tables too (this G step's pass has no dropout)
         c->dreal_noise2 = drop;
-        d_forward_rows(c, c->staged_src, 0, B, drop, c->s_c, c->slab_k2, true, false, wl);
+        d_forward_rows(c, c->staged_src, 0, B, drop, c->s_c, c->slab_k2, true);
         L.record(c->ev_dreal, c->s_c);
     }
-    d_forward_rows(c, img, r0g, B, gdrop, L.m, c->slab_k, true, conv1_done, wl);
+    d_forward_rows(c, img, r0g, B, gdrop, L.m, c->slab_k, true, conv1_done);
     d_backward_pass(c, L, img, B, img, B, gdrop, false, true, BceSpec{B, gy, gy, k.mt, 1}, r0g);   // through D into the image; no D weight grads
     if (k.pre_real && !real_early) {
         // siggan_stage_real: the NEXT D step's D(real) forward needs the Discriminator as it is now (its
@@ -1161,21 +1126,6 @@ static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     }
     const bool guard = c->dt == DT_F16;                              // static gradient scale: skip the update on an overflow
     if (clip || guard) launch_grad_sumsq(g, n, c->dev, c->partial, L.m);
-    if (k.split_tail) {
-        // Discriminator update split at the last block (make_key decides: pipelined step, one-launch optimiser, no clip, no
-        // communicator): head on the caller's stream, tail -- and the tail's weight packs -- on s_n behind the D backward's two
-        // joins.  Same elementwise arithmetic: bit-identical to the unsplit update.
-        const int64_t o = c->d_off[di_w(c->Ld)];
-        L.wait(c->s_n, c->ev_join_a); L.wait(c->s_n, c->ev_join_b);
-        float* const mskip = k.mt + SIGGAN_M_D_SKIPPED;
-        launch_adam_fused(p, g, m, v, o, c->dev, steps, nt, k.fused_t, k.lr, k.beta1, k.beta2, k.eps, gs, 0.f, nullptr, nullptr, L.m, mskip, true);
-        launch_adam_fused(p + o, g + o, m + o, v + o, n - o, c->dev, steps, nt, k.fused_t, k.lr, k.beta1, k.beta2, k.eps, gs, 0.f, nullptr,
-                          nullptr, c->s_n, nullptr, false);
-        repack(c, c->s_n, c->s_n, false, true, 0, nullptr, 0, 0, 2);
-        L.record(c->ev_dtail, c->s_n);
-        c->d_tail_pending = true; c->d_tail_clean = true;
-        return;
-    }
     if (k.fused_t > 0.0) {
         // ONE launch: the host knows the step count (apply_common), so the bias corrections are kernel arguments and
         // k_adam_prepare (a 5 us kernel plus a kernel boundary on the step's critical lane, twice per step) is not needed
@@ -1424,13 +1374,6 @@ static int apply_common(siggan_ctx* c, int which, const siggan_hyper* hp, float*
     } else {
         c->adam_t_known[wi] = false;
     }
-    if (which == 1) {
-        c->d_tail_clean = false;
-        // SIGGAN_MODE_DEFER_D_TAIL, inside a pipelined step (siggan_g_grads must follow and joins the tail where it needs it)
-        k.split_tail = DEFER_TAIL(c) && c->g_fwd_pending != 0 && k.fused_t > 0.0 && k.clip == 0.f && !c->comm && !c->sn &&
-                       (c->mode & SIGGAN_MODE_OVERLAP) != 0 && g_prof == nullptr && c->ev_join_a && c->ev_join_b &&
-                       c->variant == SIGGAN_STEP_TRAINER;
-    }
     if ((rc = run_phase(c, k, s))) return rc;
     if (k.fused_t > 0.0) c->adam_t[wi] = k.fused_t;
     if (which == 0) c->g_dirty = true; else c->d_dirty = true;
@@ -1458,7 +1401,7 @@ extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, 
     if ((rc = check_hyper(hp))) return rc;
     if (!c->st.g_grads) return fail(SIGGAN_E_STATE, "gradient arena was not bound");
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = settle(c, s, /*keep_dtail=*/!c->sn))) return rc;
+    if ((rc = settle(c, s))) return rc;
     const int B = batch;
     const bool spec = c->g_fwd_pending != 0;
     if (c->variant == SIGGAN_STEP_ABLATION && !spec)

@@ -110,19 +110,10 @@ class DataParallelStep:
         e.step_begin(real_local, z_d, masks, z_g, hp["ls"])       # D grads + the G step's forward beside them
         if not lib:
             allreduce_sum_(e.d_grads)
-        # (single replica: the tail of the D update may run beside the start of the G step, as Engine.train_step lets it;
-        #  with a communicator the library keeps the update whole)
-        defer = getattr(e, "_defer", True) and getattr(e, "_mode", 2) == 2
-        if defer:
-            e.lib.siggan_set_mode(e._h, e._mode | 4)
-        try:
-            dm = e.d_apply(hp["lr_d"], hp["beta1"], hp["beta2"], clip=hp["clip"], grad_scale=inv, sync=sync)
-            if next_real is not None:
-                e.stage_real(next_real)
-            e.g_compute_grads(real_local.shape[0])
-        finally:
-            if defer:
-                e.lib.siggan_set_mode(e._h, e._mode)
+        dm = e.d_apply(hp["lr_d"], hp["beta1"], hp["beta2"], clip=hp["clip"], grad_scale=inv, sync=sync)
+        if next_real is not None:
+            e.stage_real(next_real)
+        e.g_compute_grads(real_local.shape[0])
         if not lib:
             allreduce_sum_(e.g_grads)
         gm = e.g_apply(hp["lr_g"], hp["beta1"], hp["beta2"], clip=hp["clip"], grad_scale=inv, sync=sync)

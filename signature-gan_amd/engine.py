@@ -55,7 +55,7 @@ class Engine:
         self._h = None
         self._staged = None
         self._comm = None
-        self._mode, self._defer = 2, True          # SIGGAN_MODE_OVERLAP; train_step defers the D tail (set_mode)
+        self._mode = 2                             # SIGGAN_MODE_OVERLAP (set_mode); re-applied when the context is re-created
         self._create_context()
         h = self._h
         self.g_entries = layout.generator_entries(latent_dim, image_size)
@@ -179,12 +179,9 @@ class Engine:
         """Call after writing parameters / BN buffers from outside (load_state_dict, init)."""
         _lib.check(self.lib.siggan_params_changed(self._h))
 
-    def set_mode(self, graph=False, overlap=True, defer_d_tail=None):
-        """Step-phase execution mode: hipGraph replay and/or side-stream overlap (default: overlap only).  defer_d_tail
-        (SIGGAN_MODE_DEFER_D_TAIL; default: on with overlap and no graph): train_step lets the update of the Discriminator's
-        last block run beside the start of the G step -- bit-identical results; only the pipelined train_step uses it."""
+    def set_mode(self, graph=False, overlap=True):
+        """Step-phase execution mode: hipGraph replay and/or side-stream overlap (default: overlap only)."""
         self._mode = (1 if graph else 0) | (2 if overlap else 0)
-        self._defer = (overlap and not graph) if defer_d_tail is None else bool(defer_d_tail)
         _lib.check(self.lib.siggan_set_mode(self._h, self._mode))
 
     def set_step_variant(self, variant="trainer"):
@@ -364,19 +361,10 @@ class Engine:
         """One pipelined G+D step (n_critic = 1): same results as d_step followed by g_step.  next_real: the
         following step's real batch, if the loop already has it (see stage_real)."""
         self.step_begin(real, z_d, masks, z_g, label_smoothing)
-        # nothing here touches the Discriminator's arenas between d_apply and g_compute_grads: the tail of its update may run
-        # beside the start of the G step (include/siggan.h, SIGGAN_MODE_DEFER_D_TAIL)
-        defer = getattr(self, "_defer", True) and getattr(self, "_mode", 2) == 2
-        if defer:
-            self.lib.siggan_set_mode(self._h, self._mode | 4)
-        try:
-            dm = self.d_apply(lr_d, beta1, beta2, eps, clip, 1.0, sync)
-            if next_real is not None:
-                self.stage_real(next_real)
-            self.g_compute_grads(real.shape[0])
-        finally:
-            if defer:
-                self.lib.siggan_set_mode(self._h, self._mode)
+        dm = self.d_apply(lr_d, beta1, beta2, eps, clip, 1.0, sync)
+        if next_real is not None:
+            self.stage_real(next_real)
+        self.g_compute_grads(real.shape[0])
         gm = self.g_apply(lr_g, beta1, beta2, eps, clip, 1.0, sync)
         if sync:
             dm.update(gm)

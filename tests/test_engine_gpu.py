@@ -460,37 +460,6 @@ def test_staged_next_batch_is_bitwise_identical():
             assert torch.equal(a, b), f"{kind}: staging the next batch changed the result"
 
 
-def test_deferred_discriminator_tail_is_bitwise_identical():
-    """SIGGAN_MODE_DEFER_D_TAIL (Engine.train_step's default): the optimiser update and the weight re-packs of the
-    Discriminator's last block + classifier run on a lane of the library's own beside the start of the G step.  Same
-    elementwise arithmetic, so everything -- parameters, moments, BatchNorm statistics, metrics, and a Discriminator forward
-    issued right behind a step (another entry point: it must wait for that lane) -- equals the whole-update sequence bit for bit."""
-    from hipcommon import cuda, make_engine
-    size, latent, batch = 64, 100, 16
-    reals = [cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"] + 7 * t))) for t in range(5)]
-
-    def run(defer, staged, probe_d):
-        eng = make_engine(size, latent, batch, warm=True)
-        eng.set_mode(graph=False, overlap=True, defer_d_tail=defer)
-        eng.seed(4321)
-        mets, probes = [], []
-        for t in range(4):
-            mets.append(eng.train_step(reals[t], next_real=reals[t + 1] if staged else None))
-            if probe_d:
-                probes.append(eng.d_forward(reals[t], training=False).clone())
-        state = [x.clone() for x in (eng.g_params, eng.d_params, eng.g_exp_avg, eng.d_exp_avg, eng.d_exp_avg_sq, eng.g_bn_mean, eng.g_bn_var,
-                                     eng.d_adam_steps)]
-        eng.close()
-        return state, mets, probes
-
-    for staged, probe_d in ((True, False), (False, False), (True, True)):
-        ref_state, ref_mets, ref_p = run(False, staged, probe_d)
-        state, mets, p = run(True, staged, probe_d)
-        assert mets == ref_mets, (staged, probe_d)
-        for a, b in zip(ref_state + ref_p, state + p):
-            assert torch.equal(a, b), f"deferring the D tail changed the result (staged={staged}, probe={probe_d})"
-
-
 def test_latent_drawn_inside_the_fc_kernel():
     """Without an explicit z the fc kernel draws the latent batch itself (no separate RNG launch) and leaves it in the
     workspace for the backward pass: it must be standard normal, and feeding the same values back as an explicit z must
