@@ -281,3 +281,12 @@ print(json.dumps({"rc": rc, "seen": seen, "torch_imported": sys.modules.get("tor
         assert [r["own_stdout"] for r in rec["seen"]] == [True, False, False, False]     # ONE JSON line: rank 0's
         for r in rec["seen"]:
             assert r["cmd"][1].endswith("bench.py") and r["cmd"][2:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+
+
+def test_bench_states_the_host_core_count():
+    """bench.py's cpu_baseline carries the box's physical core count, logical CPUs and this job's share (north star: "core count
+    stated"); the probe must give sane numbers wherever it runs and never touch torch or the GPU."""
+    import bench
+    phys, logical, share = bench.host_cores()
+    assert logical >= 1 and 1 <= share <= logical
+    assert phys is None or 1 <= phys <= logical
