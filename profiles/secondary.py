@@ -2,7 +2,7 @@
 """Secondary figures ("generation throughput reported as a secondary figure"): tracked so that every
 number the record quotes is one command away.
 
-    python profiles/secondary.py [--out profiles/r03_secondary.json] [--no-trainer]
+    python profiles/secondary.py [--out profiles/r04_secondary.json] [--no-trainer]
 
   * generation -- Generator.forward in eval mode (siggan_g_forward; reference: utils/inference.py:136-194,
     vanilla_gan_model.py:338-371) at several batch sizes / both image sizes: us per batch, images/s, achieved TFLOP/s on

@@ -73,14 +73,19 @@ def hip_signs_g(eng, size, batch):
 
 def count_sign_flips(signs, recorded, keep=None):
     """Disagreements between the HIP sign decisions and the oracle's own; every one must be a
-    pre-activation within rounding of zero (|x| <= 1e-5 of the layer's scale)."""
-    n = 0
+    pre-activation within rounding of zero (|x| <= 1e-5 of the layer's scale).  Their NUMBER is bounded too, in proportion to
+    the activations compared: two fp32 implementations differ by ~1e-7 of a layer's scale, so of N inputs spread over that
+    scale about 1e-7 N (times the density at zero) land on the other side -- 16, or one per million where that is more (the
+    128x128 batch-32 steps compare 41 M activations; 12-17 were seen there across boxes, whose oracle runs with different
+    thread counts)."""
+    n, total = 0, 0
     for i, (s, x) in enumerate(zip(signs, recorded)):
+        total += x.numel()
         bad = s.reshape(x.shape) != (x > 0)
         if keep is not None and keep[i] is not None:
             bad &= keep[i][:, :, None, None] > 0          # dropped planes carry no gradient
         if bad.any():
             assert float(x[bad].abs().max()) <= 1e-5 * float(x.abs().max()), "sign disagreement away from zero"
             n += int(bad.sum())
-    assert n <= 16, f"{n} borderline sign decisions differ"
+    assert n <= max(16, total // 1000000), f"{n} borderline sign decisions differ (of {total} activations)"
     return n
