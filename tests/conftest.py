@@ -11,6 +11,15 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle is torch on the CPU.  A GPU box hands the process 128-256 CPUs and torch then starts as many threads, which
+    # makes its oneDNN convolutions at these sizes FOUR TIMES SLOWER than 16 threads do (measured on the MI355X box: the two
+    # largest three-step cases 52.9 s with the default 128 threads, 13.4 s with 16, 14.4 s with 32, 25.5 s with 64).  Results do
+    # not depend on the count: every parity test hands the oracle its sign decisions.
+    try:
+        import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except Exception:                                    # pragma: no cover
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
