@@ -6,7 +6,7 @@ def short(n):
     n = re.sub(r"^void ", "", n); n = re.sub(r"\(.*$", "", n); n = n.replace("siggan::", "")
     return n[:46]
 # find step boundaries: k_adam launches; D apply then G apply. A step = from after G adam to next G adam.
-adam = [i for i, r in enumerate(rows) if ("k_adam(" in r["Kernel_Name"] or "k_adam<" in r["Kernel_Name"])]
+adam = [i for i, r in enumerate(rows) if ("k_adam(" in r["Kernel_Name"] or "k_adam<" in r["Kernel_Name"] or "k_adam_pack" in r["Kernel_Name"])]
 print("adam launches", len(adam), file=sys.stderr)
 # choose step near the end
 k = len(adam) - 7

@@ -10,7 +10,18 @@
 // type T and go through ld4 / st4 below, so for T = float they compile to exactly the fp32 code.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+
+// `done` (the launch_* functions that take one, GConvArgs::done): the event is bound to the launch's LAST kernel as hipExtLaunchKernel's stop event -- it
+// rides on that dispatch packet's own completion signal.  A side lane forked this way (hipStreamWaitEvent on `done`) costs the
+// producing lane nothing; hipEventRecord behind the kernel is a marker packet of its own, ~5 us before the next kernel starts.
+#define SIGGAN_LAUNCH_EV(ev, kernel, grid, block, shmem, stream, ...)                                            \
+    do {                                                                                                         \
+        if (ev) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, ev, 0, __VA_ARGS__);          \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                \
+    } while (0)
+
 
 namespace siggan {
 

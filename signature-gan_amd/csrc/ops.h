@@ -89,13 +89,13 @@ void launch_bn_relu(int dt, const void* y, void* a, int64_t R, int C, const floa
 // backward through relu(BN(y)): da (in) -> dy (in place); dgamma/dbeta (torch order) written.  The relu mask is
 // re-derived from y and the layer's scale/shift (the forward's own expression), so the activation is not read.
 void launch_bn_bwd(int dt, void* da, const void* y, int64_t R, int C, float* bn, float* partial,
-                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s, int pre_rows = 0);
+                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s, int pre_rows = 0, hipEvent_t done = nullptr);
 
 // final 3x3 conv (C->1) + tanh, and its backward pieces.  act: [B][S][S][C] NHWC, img [B][S][S].
 // bn != nullptr (training): `act` is the last block's PRE-BatchNorm tensor y and bn its [scale | shift] table -- the
 // activation relu(fma(y, scale, shift)) is formed on load and never stored
 void launch_final_fwd(int dt, const void* act, const float* Wt, const float* b, float* img, int B, int S, int C, hipStream_t s,
-                      const float* bn = nullptr);
+                      const float* bn = nullptr, hipEvent_t done = nullptr);
 // backward of the last Generator block from dpre.  (1) launch_final_bwd_reduce: ONE read of y gives the BatchNorm-backward sums
 // (d(act) of the final conv recomputed from dpre, never stored; relu mask re-derived from y) into `partial` AND the partial
 // rows of the final conv's weight / bias gradient (activation re-derived from y) into `partial_w`;  (2) launch_final_bn_bwd_apply:
@@ -104,7 +104,7 @@ void launch_final_bwd_reduce(int dt, const float* dpre, const float* Wt, const v
                              float* partial, float* partial_w, hipStream_t s);
 void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* Wt, const void* y, void* dy, int B, int S, int C, float* bn,
                                const float* partial, const float* partial_w, float* dW, float* db, float* dgamma, float* dbeta,
-                               hipStream_t s);
+                               hipStream_t s, hipEvent_t done = nullptr);
 
 // ---- Discriminator pieces -----------------------------------------------------------------
 // first block (Cin = 1): x = two segments (x0: n < n0, x1: the rest), out [B][S/2][S/2][C]
@@ -188,6 +188,40 @@ void launch_adam_fused(float* p, float* g, float* m, float* v, int64_t n, DevSta
                        float* metric_norm, const float* sumsq_partial, hipStream_t s, float* metric_skipped = nullptr);
 void launch_adam(float* p, float* g, float* m, float* v, int64_t n, const DevState* st, double beta1,
                  double beta2, double eps, int write_back_grad, hipStream_t s);
+
+// ---- the one-launch update that also rebuilds what the next pass derives from the arena ------------------------------
+// launch_adam_fused plus launch_prepare's work in ONE launch: the arena is covered by a job table; a workgroup that owns a
+// 16 x 16 x 16-tap tile of a convolution weight updates it and writes both MFMA packs from LDS (64-byte runs each way), the
+// classifier / one-channel weights and the BatchNorm eval tables likewise.  Same update arithmetic, same pack values as the
+// two launches it replaces (bitwise: tests/test_engine_gpu.py compares the execution modes).
+enum ApType : int { AP_FLAT = 0, AP_CONV, AP_T16, AP_TAPS, AP_BN };
+struct ApJob {
+    int type;
+    int A, Bc;                   // CONV: the weight is [A][Bc][4][4]; T16: A rows of 16; TAPS: A channels x Bc taps; BN: A channels, Bc = perm_c0
+    int dt;                      // CONV: element type of the two packs
+    long long off, n;            // first arena element, element count (BN: off = gamma)
+    long long off2, n2;          // TAPS: a second flat range owned by the same workgroup (the layer's bias); BN: off2 = beta
+    float* dst;                  // CONV: the pack whose unit is dim 0 (PREP_PACK_DOWN); T16 / TAPS: the permuted copy; BN: the table
+    float* dst2;                 // CONV: the pack whose unit is dim 1 (PREP_PACK_UP)
+    const float* rmean;          // BN: running statistics
+    const float* rvar;
+    int wait;                    // TAPS: riders that must have read this job's ranges before it writes them (ApRide), 0: none
+};
+struct ApTable {
+    static constexpr int MAXJ = 24;
+    int njobs, overflow;
+    long long prefix[MAXJ + 1];  // prefix sums of the jobs' workgroup counts
+    ApJob job[MAXJ];
+};
+void ap_add(ApTable& t, const ApJob& j);
+// Riders: further workgroups of the same launch run the first Discriminator block's forward of B images with the block's
+// UPDATED weights, which each of them derives for itself from the arena (1088 values); the workgroup that owns those ranges
+// writes them only after every rider has read them (`counter`: one zero-initialised word, left at zero).
+struct ApRide { const float* x; void* out; int B, S, dt; float slope; long long w_off, b_off; unsigned* counter; };
+bool launch_adam_pack(const ApTable& t, float* p, float* g, float* m, float* v, DevState* st, float* steps, int ntensors,
+                      double tstep, double lr, double beta1, double beta2, double eps, float grad_scale, float clip_max_norm,
+                      float* metric_norm, const float* sumsq_partial, float* metric_skipped, float bn_eps,
+                      const ApRide* ride, hipStream_t s);
 
 // input pipeline: out[b] = lut[ resample(cache[index[b]]) ], (B,1,S,S) fp32 from an (N,S,S) uint8 cache (see k_augment)
 void launch_augment(const uint8_t* cache, int64_t n_images, const int32_t* index, const int32_t* prm, const int16_t* tabs,

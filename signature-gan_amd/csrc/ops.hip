@@ -58,6 +58,19 @@ void launch_tick(DevState* st, hipStream_t s) { hipLaunchKernelGGL(k_tick, dim3(
 
 __device__ __forceinline__ int perm16(int c, int perm_c0) { return perm_c0 > 0 ? (c % perm_c0) * 16 + c / perm_c0 : c; }
 
+// the optimiser's per-element arithmetic (k_adam, k_adam_pack and the riders of k_adam_pack share it: bitwise the same values)
+struct AdamK { float mul, ss, bc2, w1, beta2, w2, eps; };     // w1 = (float)(1 - beta1), w2 = (float)(1 - beta2): formed in double on the host, as torch does
+__device__ __forceinline__ void adam_upd(const AdamK& k, float& pp, float& gg, float& mm, float& vv) {
+    const float gr = gg * k.mul;
+    gg = gr;
+    // exp_avg.lerp_(grad, 1 - beta1)
+    mm = k.w1 < 0.5f ? mm + k.w1 * (gr - mm) : gr - (gr - mm) * (1.0f - k.w1);
+    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    vv = vv * k.beta2 + k.w2 * gr * gr;
+    const float denom = sqrtf(vv) / k.bc2 + k.eps;
+    pp = pp + (k.ss * mm) / denom;
+}
+
 // =========================================================================================
 // fused prepare pass (weight packs, fc / classifier permutes, BatchNorm eval folding)
 // =========================================================================================
@@ -407,7 +420,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_fin_apply(T* __restrict__ da, co
     }
 }
 void launch_bn_bwd(int dt, void* dav, const void* yv, int64_t R, int C, float* bn, float* partial,
-                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s, int pre_rows) {
+                   float* dgamma, float* dbeta, int perm_c0, hipStream_t s, int pre_rows, hipEvent_t done) {
     // pre_rows > 0: the kernel that produced da left that many partial rows of both sums in `partial` (gconv's
     // EPI_BN_BWD_STATS): no reduction pass over da and y
     const ColPlan pl = col_plan(R, C);
@@ -420,8 +433,8 @@ void launch_bn_bwd(int dt, void* dav, const void* yv, int64_t R, int C, float* b
         if (chunks > (R + 63) / 64) chunks = (R + 63) / 64;
         int rpc = (int)((R + chunks - 1) / chunks); rpc = ((rpc + 31) / 32) * 32;
         chunks = (R + rpc - 1) / rpc;
-        SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_bn_bwd_fin_apply<T>, dim3(slices, (unsigned)chunks), dim3(256), 0, s, (T*)dav, (const T*)yv, R, C,
-                                                    bn, p0, p1, nch, dgamma, dbeta, rpc));
+        SIGGAN_DT_SWITCH(dt, T, SIGGAN_LAUNCH_EV(done, k_bn_bwd_fin_apply<T>, dim3(slices, (unsigned)chunks), dim3(256), 0, s, (T*)dav, (const T*)yv, R, C,
+                                                  bn, p0, p1, nch, dgamma, dbeta, rpc));
         return;
     }
     SIGGAN_DT_SWITCH(dt, T, {
@@ -430,7 +443,7 @@ void launch_bn_bwd(int dt, void* dav, const void* yv, int64_t R, int C, float* b
             hipLaunchKernelGGL((k_colreduce<FBnBwd<T>>), dim3(pl.cbx, pl.nch), dim3(256), 0, s,
                                FBnBwd<T>{da, y, (const float4*)bn}, R, C, pl.cg, pl.rows, p0, p1);
         launch_bn_bwd_fin(p0, p1, nch, R, C, bn, dgamma, dbeta, perm_c0, s);
-        hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(cdiv(n4, 256)), dim3(256), 0, s, da, y, n4, C / 4, (const float4*)bn);
+        SIGGAN_LAUNCH_EV(done, k_bn_bwd_apply<T>, dim3(cdiv(n4, 256)), dim3(256), 0, s, da, y, n4, C / 4, (const float4*)bn);
     });
 }
 
@@ -639,12 +652,12 @@ __global__ __launch_bounds__(256) void k_final_fwd(const T* __restrict__ act, co
     }
 }
 void launch_final_fwd(int dt, const void* act, const float* Wt, const float* b, float* img, int B, int S, int C, hipStream_t s,
-                      const float* bn) {
+                      const float* bn, hipEvent_t done) {
     (void)C;                                            // host checks C == 32, S % 32 == 0
     const dim3 grid(B * (S / 4) * (S / 32));
     SIGGAN_DT_SWITCH(dt, T, {
-        if (bn) hipLaunchKernelGGL((k_final_fwd<T, true>), grid, dim3(256), 0, s, (const T*)act, Wt, b, img, S, bn);
-        else hipLaunchKernelGGL((k_final_fwd<T, false>), grid, dim3(256), 0, s, (const T*)act, Wt, b, img, S, bn);
+        if (bn) SIGGAN_LAUNCH_EV(done, (k_final_fwd<T, true>), grid, dim3(256), 0, s, (const T*)act, Wt, b, img, S, bn);
+        else SIGGAN_LAUNCH_EV(done, (k_final_fwd<T, false>), grid, dim3(256), 0, s, (const T*)act, Wt, b, img, S, bn);
     });
 }
 
@@ -882,13 +895,13 @@ void launch_final_bwd_reduce(int dt, const float* dpre, const float* Wt, const v
 }
 void launch_final_bn_bwd_apply(int dt, const float* dpre, const float* Wt, const void* y, void* dy, int B, int S, int C, float* bn,
                                const float* partial, const float* partial_w, float* dW, float* db, float* dgamma, float* dbeta,
-                               hipStream_t s) {
+                               hipStream_t s, hipEvent_t done) {
     const int nstrips = B * (S / 4) * (S / 32), nch = final_reduce_rows(B, S);
     const float* p0 = partial; const float* p1 = partial + (size_t)nch * C;
     const int nbw = cdiv(C * 9 + 1, 64);
     hipLaunchKernelGGL(k_final_fin, dim3(nbw + cdiv(C, 32)), dim3(1024), 0, s, partial_w, nch, C * 9 + 1, dW, C * 9, db, nbw, p0, p1, nch,
                        (int64_t)B * S * S, C, bn, dgamma, dbeta);
-    SIGGAN_DT_SWITCH(dt, T, hipLaunchKernelGGL(k_final_bnbwd_apply<T>, dim3(nstrips), dim3(256), 0, s, dpre, Wt, (const T*)y, bn, (T*)dy, S));
+    SIGGAN_DT_SWITCH(dt, T, SIGGAN_LAUNCH_EV(done, k_final_bnbwd_apply<T>, dim3(nstrips), dim3(256), 0, s, dpre, Wt, (const T*)y, bn, (T*)dy, S));
 }
 
 // =========================================================================================
@@ -910,23 +923,46 @@ __device__ __forceinline__ void stage_x(float* sx, const float* xp, int oh0, int
 // thread = 4 output channels (16 taps x 4 weights in registers); 16 channel lanes x 16 pixel lanes;
 // a block produces RY output rows of one image from an LDS copy of the input rows (broadcast reads)
 // and writes 256 contiguous bytes per pixel.
-template <class T>
+// RIDE (k_adam_pack's riders): W and b are the arena's values BEFORE this launch's update; the block forms the updated ones
+// itself (same arithmetic as the workgroup that owns them) and reports that it has read them
+struct Conv1Ride { const float *pw, *gw, *mw, *vw, *pb, *gb, *mb, *vb; unsigned* counter; AdamK k; };
+template <class T, bool RIDE = false>
 __device__ __forceinline__ void conv1_fwd_block(const float* __restrict__ x0, int n0, const float* __restrict__ x1,
                                                 const float* __restrict__ W, const float* __restrict__ b,
                                                 const float* __restrict__ noise, float slope,
-                                                T* __restrict__ out, int S, unsigned bid) {
+                                                T* __restrict__ out, int S, unsigned bid, const Conv1Ride* rd = nullptr) {
     constexpr int RY = 2, C = 64;
     __shared__ float sx[(2 * RY + 2) * 130];
     __shared__ __attribute__((aligned(16))) float sw[16 * (C + 4)];  // weights transposed to [tap][co] (row stride C + 4: conflict-free both ways)
+    __shared__ __attribute__((aligned(16))) float sb[RIDE ? C : 4];
     const int Ho = S >> 1, nby = Ho / RY, Wp = S + 2;
     const int n = bid / nby, oh0 = (bid % nby) * RY;
     const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
     stage_x<RY>(sx, seg_ptr(x0, n0, x1, n, S), oh0, S);
-    for (int i = threadIdx.x; i < 16 * C; i += 256) sw[(i & 15) * (C + 4) + (i >> 4)] = W[i];
-    const f4v bias = ldg4(b + q * 4);
+    f4v bias;
+    if (RIDE) {
+        for (int i = threadIdx.x; i < 16 * C; i += 256) {
+            float pp = rd->pw[i], gg = rd->gw[i], mm = rd->mw[i], vv = rd->vw[i];
+            adam_upd(rd->k, pp, gg, mm, vv);
+            sw[(i & 15) * (C + 4) + (i >> 4)] = pp;
+        }
+        if (threadIdx.x < C) {
+            float pp = rd->pb[threadIdx.x], gg = rd->gb[threadIdx.x], mm = rd->mb[threadIdx.x], vv = rd->vb[threadIdx.x];
+            adam_upd(rd->k, pp, gg, mm, vv);
+            sb[threadIdx.x] = pp;
+        }
+    } else {
+        for (int i = threadIdx.x; i < 16 * C; i += 256) sw[(i & 15) * (C + 4) + (i >> 4)] = W[i];
+        bias = ldg4(b + q * 4);
+    }
     f4v nz = {1.f, 1.f, 1.f, 1.f};
     if (noise) nz = ldg4(noise + (size_t)n * C + q * 4);
     __syncthreads();
+    if (RIDE) {
+        // every value this block needs of the ranges is in LDS: the owner may overwrite them (relaxed: the loads have completed)
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(rd->counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bias = *reinterpret_cast<const f4v*>(sb + q * 4);
+    }
     f4v w[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const f4v*>(sw + t * (C + 4) + q * 4);
@@ -1446,75 +1482,74 @@ struct AdamHost {          // scalars of a fused update, formed on the host (FUS
     float* metric_skipped;        // the step's "update skipped" flag: a fused update never skips, it writes 0 (include/siggan.h)
     const float* sumsq_partial;   // k_sumsq's block partials (clip): every block's wave 0 adds them itself
 };
+// multiplier / step size / bias correction of a fused update (every workgroup of the launch; contains a barrier when clipping),
+// and what k_adam_prepare does besides the scalars (workgroup 0)
+__device__ __forceinline__ void adam_fused_scalars(const AdamHost& h, DevState* st, AdamK& k) {
+    k.mul = h.grad_scale; k.ss = -h.step_size; k.bc2 = h.bc2_sqrt;
+    float norm = 0.f;
+    if (h.clip_max_norm > 0.f) {                                   // nn.utils.clip_grad_norm_ (norm_type 2), k_adam_prepare's expression
+        __shared__ float s_ssq;
+        if (threadIdx.x < 64) {
+            const float ssq = sum_partials_wave(h.sumsq_partial, SUMSQ_BLOCKS, threadIdx.x);
+            if (threadIdx.x == 0) s_ssq = ssq;
+        }
+        __syncthreads();
+        norm = sqrtf(s_ssq) * h.grad_scale;
+        k.mul = h.grad_scale * fminf(h.clip_max_norm / (norm + 1e-6f), 1.0f);
+    }
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < h.ntensors; i += 256) h.steps[i] = h.t;
+        if (threadIdx.x == 0) {
+            st->rng_ctr += 1;                                      // every optimiser update starts a new RNG epoch
+            st->skip = 0;
+            if (h.metric_skipped) *h.metric_skipped = 0.0f;
+            if (h.clip_max_norm > 0.f) { st->grad_norm = norm; if (h.metric_norm) *h.metric_norm = norm; }
+        }
+    }
+}
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                               float4* __restrict__ v, int64_t n4, float* __restrict__ pt,
                                               float* __restrict__ gt, float* __restrict__ mt, float* __restrict__ vt,
                                               int tail, DevState* __restrict__ st, float w1, float beta2,
                                               float w2, float eps, int wb, const AdamHost h) {
-    // w1 = (float)(1 - beta1), w2 = (float)(1 - beta2): formed in double on the host, as torch does
-    float mul, ss, bc2;
+    AdamK k; k.w1 = w1; k.beta2 = beta2; k.w2 = w2; k.eps = eps;
     if (FUSED) {
-        mul = h.grad_scale; ss = -h.step_size; bc2 = h.bc2_sqrt;
-        float norm = 0.f;
-        if (h.clip_max_norm > 0.f) {                                   // nn.utils.clip_grad_norm_ (norm_type 2), k_adam_prepare's expression
-            __shared__ float s_ssq;
-            if (threadIdx.x < 64) {
-                const float ssq = sum_partials_wave(h.sumsq_partial, SUMSQ_BLOCKS, threadIdx.x);
-                if (threadIdx.x == 0) s_ssq = ssq;
-            }
-            __syncthreads();
-            norm = sqrtf(s_ssq) * h.grad_scale;
-            mul = h.grad_scale * fminf(h.clip_max_norm / (norm + 1e-6f), 1.0f);
-        }
-        if (blockIdx.x == 0) {                                         // what k_adam_prepare does besides the scalars
-            for (int i = threadIdx.x; i < h.ntensors; i += 256) h.steps[i] = h.t;
-            if (threadIdx.x == 0) {
-                st->rng_ctr += 1;                                      // every optimiser update starts a new RNG epoch
-                st->skip = 0;
-                if (h.metric_skipped) *h.metric_skipped = 0.0f;
-                if (h.clip_max_norm > 0.f) { st->grad_norm = norm; if (h.metric_norm) *h.metric_norm = norm; }
-            }
-        }
+        adam_fused_scalars(h, st, k);
     } else {
         if (st->skip) return;               // (uniform: k_adam_prepare found a non-finite fp16 gradient)
-        mul = st->grad_mul; ss = -st->step_size; bc2 = st->bc2_sqrt;
+        k.mul = st->grad_mul; k.ss = -st->step_size; k.bc2 = st->bc2_sqrt;
     }
-    auto upd = [&](float& pp, float& gg, float& mm, float& vv) {
-        const float gr = gg * mul;
-        gg = gr;
-        // exp_avg.lerp_(grad, 1 - beta1)
-        mm = w1 < 0.5f ? mm + w1 * (gr - mm) : gr - (gr - mm) * (1.0f - w1);
-        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-        vv = vv * beta2 + w2 * gr * gr;
-        const float denom = sqrtf(vv) / bc2 + eps;
-        pp = pp + (ss * mm) / denom;
-    };
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) {
         float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
-        upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y);
-        upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+        adam_upd(k, pp.x, gg.x, mm.x, vv.x); adam_upd(k, pp.y, gg.y, mm.y, vv.y);
+        adam_upd(k, pp.z, gg.z, mm.z, vv.z); adam_upd(k, pp.w, gg.w, mm.w, vv.w);
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (wb) g[i] = gg;
     } else if (i - n4 < tail) {
-        const int k = (int)(i - n4);
-        float pp = pt[k], gg = gt[k], mm = mt[k], vv = vt[k];
-        upd(pp, gg, mm, vv);
-        pt[k] = pp; mt[k] = mm; vt[k] = vv;
-        if (wb) gt[k] = gg;
+        const int e = (int)(i - n4);
+        float pp = pt[e], gg = gt[e], mm = mt[e], vv = vt[e];
+        adam_upd(k, pp, gg, mm, vv);
+        pt[e] = pp; mt[e] = mm; vt[e] = vv;
+        if (wb) gt[e] = gg;
     }
+}
+static AdamHost adam_host(double t, double lr, double beta1, double beta2, float grad_scale, float clip_max_norm, float* steps,
+                          int ntensors, float* metric_norm, float* metric_skipped, const float* sumsq_partial) {
+    AdamHost h;
+    h.step_size = (float)(lr / (1.0 - pow_step(beta1, t)));            // torch.optim.Adam: lr / (1 - beta1**step), in double
+    h.bc2_sqrt = (float)sqrt(1.0 - pow_step(beta2, t));
+    h.grad_scale = grad_scale; h.clip_max_norm = clip_max_norm; h.t = (float)t; h.ntensors = ntensors; h.steps = steps;
+    h.metric_norm = metric_norm; h.metric_skipped = metric_skipped; h.sumsq_partial = sumsq_partial;
+    return h;
 }
 void launch_adam_fused(float* p, float* g, float* m, float* v, int64_t n, DevState* st, float* steps, int ntensors, double t,
                        double lr, double beta1, double beta2, double eps, float grad_scale, float clip_max_norm,
                        float* metric_norm, const float* sumsq_partial, hipStream_t s, float* metric_skipped) {
     const int64_t n4 = n / 4;
     const int tail = (int)(n - n4 * 4);
-    AdamHost h;
-    h.step_size = (float)(lr / (1.0 - pow_step(beta1, t)));            // torch.optim.Adam: lr / (1 - beta1**step), in double
-    h.bc2_sqrt = (float)sqrt(1.0 - pow_step(beta2, t));
-    h.grad_scale = grad_scale; h.clip_max_norm = clip_max_norm; h.t = (float)t; h.ntensors = ntensors; h.steps = steps;
-    h.metric_norm = metric_norm; h.metric_skipped = metric_skipped; h.sumsq_partial = sumsq_partial;
+    const AdamHost h = adam_host(t, lr, beta1, beta2, grad_scale, clip_max_norm, steps, ntensors, metric_norm, metric_skipped, sumsq_partial);
     const int wb = (clip_max_norm > 0.f || grad_scale != 1.0f) ? 1 : 0;
     hipLaunchKernelGGL(k_adam<true>, dim3(cdiv(n4 + tail, 256)), dim3(256), 0, s, (float4*)p, (float4*)g, (float4*)m, (float4*)v,
                        n4, p + n4 * 4, g + n4 * 4, m + n4 * 4, v + n4 * 4, tail, st, (float)(1.0 - beta1), (float)beta2,
@@ -1527,6 +1562,174 @@ void launch_adam(float* p, float* g, float* m, float* v, int64_t n, const DevSta
     hipLaunchKernelGGL(k_adam<false>, dim3(cdiv(n4 + tail, 256)), dim3(256), 0, s, (float4*)p, (float4*)g, (float4*)m, (float4*)v,
                        n4, p + n4 * 4, g + n4 * 4, m + n4 * 4, v + n4 * 4, tail, const_cast<DevState*>(st), (float)(1.0 - beta1),
                        (float)beta2, (float)(1.0 - beta2), (float)eps, write_back_grad, AdamHost{});
+}
+
+
+// =========================================================================================
+// k_adam_pack: the optimiser update and everything launch_prepare derives from the arena, one launch
+// =========================================================================================
+static long long ap_units(const ApJob& j) {
+    switch (j.type) {
+        case AP_FLAT: return (j.n + 1023) / 1024;
+        case AP_CONV: return (long long)(j.A / 16) * (j.Bc / 16);
+        case AP_TAPS: return 1;
+        default: return (j.A + 255) / 256;       // T16 / BN: 256 rows / channels per workgroup
+    }
+}
+void ap_add(ApTable& t, const ApJob& j) {
+    if (t.njobs >= ApTable::MAXJ) { t.overflow = 1; return; }
+    if (t.njobs == 0) t.prefix[0] = 0;
+    t.job[t.njobs] = j;
+    t.prefix[t.njobs + 1] = t.prefix[t.njobs] + ap_units(j);
+    ++t.njobs;
+}
+struct ApArena { float *p, *g, *m, *v; int wb; };
+__device__ __forceinline__ void ap_put(float* dst, int dt, size_t idx, float v) {
+    if (dt == DT_F32) dst[idx] = v;
+    else if (dt == DT_BF16) reinterpret_cast<bf16_t*>(dst)[idx] = (bf16_t)v;
+    else reinterpret_cast<f16_t*>(dst)[idx] = (f16_t)v;
+}
+// one element / one aligned group of four: update in place, return the new parameter(s)
+__device__ __forceinline__ float ap_upd1(const ApArena& a, const AdamK& k, size_t e) {
+    float pp = a.p[e], gg = a.g[e], mm = a.m[e], vv = a.v[e];
+    adam_upd(k, pp, gg, mm, vv);
+    a.p[e] = pp; a.m[e] = mm; a.v[e] = vv;
+    if (a.wb) a.g[e] = gg;
+    return pp;
+}
+__device__ __forceinline__ float4 ap_upd4(const ApArena& a, const AdamK& k, size_t e) {
+    float4 pp = *reinterpret_cast<const float4*>(a.p + e), gg = *reinterpret_cast<const float4*>(a.g + e);
+    float4 mm = *reinterpret_cast<const float4*>(a.m + e), vv = *reinterpret_cast<const float4*>(a.v + e);
+    adam_upd(k, pp.x, gg.x, mm.x, vv.x); adam_upd(k, pp.y, gg.y, mm.y, vv.y);
+    adam_upd(k, pp.z, gg.z, mm.z, vv.z); adam_upd(k, pp.w, gg.w, mm.w, vv.w);
+    *reinterpret_cast<float4*>(a.p + e) = pp; *reinterpret_cast<float4*>(a.m + e) = mm; *reinterpret_cast<float4*>(a.v + e) = vv;
+    if (a.wb) *reinterpret_cast<float4*>(a.g + e) = gg;
+    return pp;
+}
+static constexpr int AP_TS = 273;          // LDS tile of a CONV unit: [a][b][tap] at a * 273 + b * 17 + tap (odd strides: conflict-free both ways)
+__device__ __forceinline__ void ap_unit(const ApTable& t, const ApArena& a, const AdamK& k, float bn_eps, unsigned bid, unsigned* counter) {
+    extern __shared__ float tile[];
+    int j = 0;
+    while ((long long)bid >= t.prefix[j + 1]) ++j;
+    const ApJob& q = t.job[j];
+    const int u = (int)(bid - t.prefix[j]);
+    const int tid = threadIdx.x;
+    if (q.type == AP_CONV) {
+        const int ntb = q.Bc >> 4, a0 = (u / ntb) * 16, b0 = (u % ntb) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = tid + 256 * r, al = f >> 6, rr = f & 63;        // float4 f of the tile: row a0 + al, 64 float4 of 16 b x 16 taps
+            const float4 w = ap_upd4(a, k, (size_t)q.off + ((size_t)(a0 + al) * q.Bc + b0) * 16 + rr * 4);
+            float* d = tile + al * AP_TS + (rr >> 2) * 17 + (rr & 3) * 4;
+            d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+        }
+        __syncthreads();
+        // unit = dim 0 (PREP_PACK_DOWN, I = Bc): dst[a][tap * Bc + b]
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int e = tid + 256 * r, bl = e & 15, tap = (e >> 4) & 15, al = e >> 8;
+            ap_put(q.dst, q.dt, ((size_t)(a0 + al) * 16 + tap) * q.Bc + b0 + bl, tile[al * AP_TS + bl * 17 + tap]);
+        }
+        // unit = dim 1 (PREP_PACK_UP, I = A, O = Bc): dst[cls][b][t * A + a], the four taps of each output-parity class
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int e = tid + 256 * r, al = e & 15, ct = (e >> 4) & 15, bl = e >> 8;
+            const int cls = ct >> 2, tt = ct & 3;
+            const int kh = 1 - (cls >> 1) + 2 * (tt >> 1), kw = 1 - (cls & 1) + 2 * (tt & 1);
+            ap_put(q.dst2, q.dt, (((size_t)cls * q.Bc + b0 + bl) * 4 + tt) * q.A + a0 + al, tile[al * AP_TS + bl * 17 + kh * 4 + kw]);
+        }
+    } else if (q.type == AP_FLAT) {
+        const long long e = (long long)u * 1024 + tid * 4;
+        if (e + 4 <= q.n && ((q.off + e) & 3) == 0) ap_upd4(a, k, (size_t)(q.off + e));
+        else for (long long i = e; i < e + 4 && i < q.n; ++i) ap_upd1(a, k, (size_t)(q.off + i));
+    } else if (q.type == AP_T16) {                // [A][16] -> dst[16][A] (the classifier weight in the last block's NHWC order)
+        const int r0 = u * 256, nr = min(256, q.A - r0);
+        for (int f = tid; f < nr * 4; f += 256) {
+            const float4 w = ap_upd4(a, k, (size_t)q.off + (size_t)r0 * 16 + f * 4);
+            float* d = tile + (f >> 2) * 17 + (f & 3) * 4;
+            d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+        }
+        __syncthreads();
+        for (int e = tid; e < nr * 16; e += 256) { const int tap = e / nr, rl = e - tap * nr; q.dst[(size_t)tap * q.A + r0 + rl] = tile[rl * 17 + tap]; }
+    } else if (q.type == AP_TAPS) {               // one-channel convs: w[c][tap] -> dst[tap][c]; <= 1024 weights (+ <= 256 bias values)
+        float pp[4], gg[4], mm[4], vv[4], pb = 0.f, gb = 0.f, mb = 0.f, vb = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;
+            if (e < q.n) { pp[r] = a.p[q.off + e]; gg[r] = a.g[q.off + e]; mm[r] = a.m[q.off + e]; vv[r] = a.v[q.off + e]; adam_upd(k, pp[r], gg[r], mm[r], vv[r]); }
+        }
+        if (tid < q.n2) { pb = a.p[q.off2 + tid]; gb = a.g[q.off2 + tid]; mb = a.m[q.off2 + tid]; vb = a.v[q.off2 + tid]; adam_upd(k, pb, gb, mb, vb); }
+        if (q.wait > 0) {
+            // the riders form these values from the ranges as they are NOW: nothing is written until all of them have read
+            // (bounded: a rider never waits, so the count is reached as soon as the last one has been dispatched)
+            if (tid == 0) {
+                unsigned it = 0;
+                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)q.wait && ++it < (1u << 20))
+                    __builtin_amdgcn_s_sleep(16);
+                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;
+            if (e < q.n) {
+                a.p[q.off + e] = pp[r]; a.m[q.off + e] = mm[r]; a.v[q.off + e] = vv[r];
+                if (a.wb) a.g[q.off + e] = gg[r];
+                q.dst[(size_t)(e % q.Bc) * q.A + e / q.Bc] = pp[r];
+            }
+        }
+        if (tid < q.n2) {
+            a.p[q.off2 + tid] = pb; a.m[q.off2 + tid] = mb; a.v[q.off2 + tid] = vb;
+            if (a.wb) a.g[q.off2 + tid] = gb;
+        }
+    } else {                                      // BN: gamma / beta of 256 channels, then [scale | shift | mean | rstd] (prepare_unit's expressions)
+        const int C = q.A, c = u * 256 + tid;
+        if (c < C) {
+            const int tix = perm16(c, q.Bc);
+            const float gam = ap_upd1(a, k, (size_t)q.off + tix), bet = ap_upd1(a, k, (size_t)q.off2 + tix);
+            const float rstd = 1.0f / sqrtf(q.rvar[tix] + bn_eps);
+            const float sc = gam * rstd;
+            q.dst[c] = sc; q.dst[C + c] = bet - q.rmean[tix] * sc; q.dst[2 * C + c] = q.rmean[tix]; q.dst[3 * C + c] = rstd;
+        }
+    }
+}
+struct ApRideDev { const float* x; void* out; int B, S; float slope; long long w_off, b_off; };
+template <class T, bool RIDE>
+__global__ __launch_bounds__(256) void k_adam_pack(const ApTable t, const ApArena a, DevState* __restrict__ st, float w1, float beta2,
+                                                   float w2, float eps, const AdamHost h, float bn_eps, unsigned nprep,
+                                                   const ApRideDev r, unsigned* counter) {
+    AdamK k; k.w1 = w1; k.beta2 = beta2; k.w2 = w2; k.eps = eps;
+    adam_fused_scalars(h, st, k);
+    if (blockIdx.x < nprep) { ap_unit(t, a, k, bn_eps, blockIdx.x, counter); return; }
+    if (RIDE) {
+        Conv1Ride rd;
+        rd.pw = a.p + r.w_off; rd.gw = a.g + r.w_off; rd.mw = a.m + r.w_off; rd.vw = a.v + r.w_off;
+        rd.pb = a.p + r.b_off; rd.gb = a.g + r.b_off; rd.mb = a.m + r.b_off; rd.vb = a.v + r.b_off;
+        rd.counter = counter; rd.k = k;
+        conv1_fwd_block<T, true>(r.x, r.B, r.x, nullptr, nullptr, nullptr, r.slope, (T*)r.out, r.S, blockIdx.x - nprep, &rd);
+    }
+}
+bool launch_adam_pack(const ApTable& t, float* p, float* g, float* m, float* v, DevState* st, float* steps, int ntensors,
+                      double tstep, double lr, double beta1, double beta2, double eps, float grad_scale, float clip_max_norm,
+                      float* metric_norm, const float* sumsq_partial, float* metric_skipped, float bn_eps,
+                      const ApRide* ride, hipStream_t s) {
+    if (t.overflow || t.njobs == 0) return false;
+    const AdamHost h = adam_host(tstep, lr, beta1, beta2, grad_scale, clip_max_norm, steps, ntensors, metric_norm, metric_skipped, sumsq_partial);
+    ApArena a; a.p = p; a.g = g; a.m = m; a.v = v; a.wb = (clip_max_norm > 0.f || grad_scale != 1.0f) ? 1 : 0;
+    const unsigned nprep = (unsigned)t.prefix[t.njobs];
+    const size_t lds = (size_t)(16 * AP_TS) * sizeof(float);        // CONV tile 16 x 273 (T16: 256 x 17 fits)
+    const float fw1 = (float)(1.0 - beta1), fb2 = (float)beta2, fw2 = (float)(1.0 - beta2), fe = (float)eps;
+    if (!ride) {
+        hipLaunchKernelGGL((k_adam_pack<float, false>), dim3(nprep), dim3(256), lds, s, t, a, st, fw1, fb2, fw2, fe, h, bn_eps, nprep,
+                           ApRideDev{}, (unsigned*)nullptr);
+        return true;
+    }
+    ApRideDev r; r.x = ride->x; r.out = ride->out; r.B = ride->B; r.S = ride->S; r.slope = ride->slope; r.w_off = ride->w_off; r.b_off = ride->b_off;
+    const unsigned nride = (unsigned)(ride->B * (ride->S / 4));
+    SIGGAN_DT_SWITCH(ride->dt, T, hipLaunchKernelGGL((k_adam_pack<T, true>), dim3(nprep + nride), dim3(256), lds, s, t, a, st, fw1, fb2, fw2, fe,
+                                                      h, bn_eps, nprep, r, ride->counter));
+    return true;
 }
 
 }  // namespace siggan

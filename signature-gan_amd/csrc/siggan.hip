@@ -124,11 +124,14 @@ struct PhaseKey {
     float* mt;   // where the phase writes its metrics (caller's buffer, or the workspace one)
     double lr, beta1, beta2, eps;
     double fused_t;   // > 0: the step count (after the increment) of a one-launch optimiser update; 0: k_adam_prepare path
+    int pack;         // apply: that launch also rebuilds the weight packs / eval tables (k_adam_pack)
+    int ride;         // D apply: ... and runs the first Discriminator block of the pending G step's `ride` images (its riders)
+    int rode;         // G grads: the preceding D apply did
     float ls, clip, gs;
     bool operator==(const PhaseKey& o) const {
         return phase == o.phase && B == o.B && has_z == o.has_z && has_masks == o.has_masks && g_dirty == o.g_dirty &&
                d_dirty == o.d_dirty && spec_g == o.spec_g && has_zg == o.has_zg && pre_real == o.pre_real && variant == o.variant && coll == o.coll && mt == o.mt && lr == o.lr && beta1 == o.beta1 && beta2 == o.beta2 && eps == o.eps && ls == o.ls &&
-               clip == o.clip && gs == o.gs && fused_t == o.fused_t;
+               clip == o.clip && gs == o.gs && fused_t == o.fused_t && pack == o.pack && ride == o.ride && rode == o.rode;
     }
 };
 
@@ -194,6 +197,8 @@ struct siggan_ctx {
     int dreal_B;         // batch whose D(real) forward siggan_g_grads already enqueued on lane c (0: none)
     int zg_stash;        // batch of an explicit G-step z handed to siggan_step_begin when the forward was not pipelined
     int g_fwd_pending;   // batch of a Generator training forward already enqueued by siggan_step_begin (0: none)
+    int conv1_rode;      // batch whose first-Discriminator-block forward (workspace rows [B, 2B), updated weights) the last D apply ran
+    float* ride_ctr;     // k_adam_pack's rider count (one word, zero between launches)
     double adam_t[2];    // step count of the network's Adam state as the HOST knows it ([0] G, [1] D); valid while adam_t_known
     bool adam_t_known[2];// (reset by siggan_bind / siggan_params_changed: the caller may have written the step tensors)
     int g_r0;            // first workspace row of the Discriminator pass of the last G step (0, or B: beside an early D(real))
@@ -362,6 +367,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
         carve(&c->wfc_t, (int64_t)c->F * c->latent);
         carve(&c->wfin_t, (int64_t)9 * c->gC[c->Lg]);
         carve(&c->d_w1t, (int64_t)16 * c->dC[1]);
+        carve(&c->ride_ctr, 64);
         float* devp = nullptr;
         carve(&devp, 64);
         if (pass == 1) c->dev = (DevState*)devp;
@@ -391,7 +397,7 @@ extern "C" int siggan_create(const siggan_config* cfg, siggan_ctx** out) {
     c->staged_B = c->dreal_B = 0; c->staged_src = nullptr; c->dreal_joined = c->dreal_noise2 = c->gfwd_joined = false;
     c->dreal_orphan = false; c->lane_err = hipSuccess;
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1; c->comm_err = 0;
-    c->g_fwd_pending = 0;
+    c->g_fwd_pending = 0; c->conv1_rode = 0;
     c->zg_stash = 0;
     c->ga_last_B = 0; c->g_r0 = 0;
     c->adam_t_known[0] = c->adam_t_known[1] = false;
@@ -490,7 +496,7 @@ extern "C" int siggan_bind(siggan_ctx* c, const siggan_storage* st) {
         t.u = st->d_sn_u; t.v = st->d_sn_v; t.tbuf = c->sn_tbuf; t.wbuf = c->sn_wbuf; t.sig = c->sn_sig;
         t.u_saved = c->sn_us; t.v_saved = c->sn_vs; t.dots = c->sn_dots; t.u_total = uo; t.v_total = vo;
     }
-    c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0; c->staged_B = 0;
+    c->bound = true; c->g_dirty = c->d_dirty = true; c->pending = 0; c->staged_B = 0; c->conv1_rode = 0;
     c->adam_t_known[0] = c->adam_t_known[1] = false;
     c->early_ar = false;               // (an early all-reduce whose apply never ran is abandoned with the gradients it covered)
     drop_dreal(c);
@@ -499,6 +505,7 @@ extern "C" int siggan_bind(siggan_ctx* c, const siggan_storage* st) {
 extern "C" int siggan_params_changed(siggan_ctx* c) {
     if (!c) return fail(SIGGAN_E_INVALID, "null context");
     c->g_dirty = c->d_dirty = true;
+    c->conv1_rode = 0;                 // (a first-block forward the last D apply ran ahead used the old weights too)
     c->adam_t_known[0] = c->adam_t_known[1] = false;      // (optimizer.load_state_dict writes the step tensors)
     c->early_ar = false;
     drop_dreal(c);                     // a D(real) forward started ahead of time used the old weights
@@ -616,6 +623,64 @@ static void repack(siggan_ctx* c, hipStream_t sg, hipStream_t sd, bool do_g, boo
     }
 }
 
+// The job tables of the one-launch update (launch_adam_pack): the whole arena, tensor by tensor, with what launch_prepare
+// would derive from each.  false: this context keeps the two-launch path (the generic fc kernel's k-major copy, channel
+// counts the 16 x 16 tiles do not divide).
+static bool ap_table_g(siggan_ctx* c, ApTable& t) {
+    if (!c->fc_fused || c->gC[c->Lg] * 9 > 1024) return false;
+    for (int l = 0; l <= c->Lg; ++l) if (c->gC[l] % 16) return false;
+    t.njobs = 0; t.overflow = 0;
+    ApJob j;
+    memset(&j, 0, sizeof j);                                           // fc weight + bias: adjacent in the arena, nothing derived
+    j.type = AP_FLAT; j.off = c->g_off[gi_fc_w()]; j.n = c->g_num[gi_fc_w()] + c->g_num[gi_fc_b()];
+    ap_add(t, j);
+    for (int l = 0; l <= c->Lg; ++l) {
+        if (l > 0) {
+            memset(&j, 0, sizeof j);                                   // (Cin, Cout, 4, 4): forward contracts Cin, input-gradient Cout
+            j.type = AP_CONV; j.A = c->gC[l - 1]; j.Bc = c->gC[l]; j.dt = c->dt; j.off = c->g_off[gi_up_w(l)];
+            j.dst = (float*)c->g_dn[l]; j.dst2 = (float*)c->g_up[l];
+            ap_add(t, j);
+        }
+        memset(&j, 0, sizeof j);
+        j.type = AP_BN; j.A = l == 0 ? c->F : c->gC[l]; j.Bc = l == 0 ? c->gC[0] : 0;
+        j.off = c->g_off[gi_bn_w(l)]; j.off2 = c->g_off[gi_bn_b(l)];
+        j.rmean = c->st.g_bn_running_mean + c->g_bn_off[l]; j.rvar = c->st.g_bn_running_var + c->g_bn_off[l];
+        j.dst = c->g_bne[l];
+        ap_add(t, j);
+    }
+    memset(&j, 0, sizeof j);                                           // final conv: [tap][c] for the strip kernels, and its bias
+    j.type = AP_TAPS; j.A = c->gC[c->Lg]; j.Bc = 9; j.off = c->g_off[gi_fin_w(c)]; j.n = 9 * c->gC[c->Lg];
+    j.off2 = c->g_off[gi_fin_b(c)]; j.n2 = 1; j.dst = c->wfin_t;
+    ap_add(t, j);
+    return !t.overflow;
+}
+static bool ap_table_d(siggan_ctx* c, ApTable& t, int nride) {
+    if (c->sn || c->dC[1] * 16 > 1024 || c->dC[1] > 256) return false;     // (spectral norm: the packs follow sigma, not the update)
+    for (int l = 1; l <= c->Ld; ++l) if (c->dC[l] % 16) return false;
+    t.njobs = 0; t.overflow = 0;
+    ApJob j;
+    memset(&j, 0, sizeof j);                                           // block 1 (weight + bias: what the riders read) first
+    j.type = AP_TAPS; j.A = c->dC[1]; j.Bc = 16; j.off = c->d_off[di_w(1)]; j.n = 16 * c->dC[1];
+    j.off2 = c->d_off[di_b(1)]; j.n2 = c->dC[1]; j.dst = c->d_w1t; j.wait = nride;
+    ap_add(t, j);
+    for (int l = 2; l <= c->Ld; ++l) {
+        memset(&j, 0, sizeof j);                                       // (Cout, Cin, 4, 4): forward contracts Cin, input-gradient Cout
+        j.type = AP_CONV; j.A = c->dC[l]; j.Bc = c->dC[l - 1]; j.dt = c->dt; j.off = c->d_off[di_w(l)];
+        j.dst = (float*)c->d_dn[l]; j.dst2 = (float*)c->d_up[l];
+        ap_add(t, j);
+        memset(&j, 0, sizeof j);
+        j.type = AP_FLAT; j.off = c->d_off[di_b(l)]; j.n = c->dC[l];
+        ap_add(t, j);
+    }
+    memset(&j, 0, sizeof j);
+    j.type = AP_T16; j.A = c->dC[c->Ld]; j.off = c->d_off[di_cls_w(c)]; j.dst = c->wcp;
+    ap_add(t, j);
+    memset(&j, 0, sizeof j);
+    j.type = AP_FLAT; j.off = c->d_off[di_cls_b(c)]; j.n = 1;
+    ap_add(t, j);
+    return !t.overflow;
+}
+
 // ------------------------------------------------------------------------------------------
 // lanes: where a phase enqueues its kernels.  m is the main lane; a and b are side lanes that run
 // independent work (weight gradients, bias / BatchNorm reductions) beside the main chain.  With
@@ -633,6 +698,16 @@ static int lane_check(siggan_ctx* c) {
 struct Lanes {
     siggan_ctx* c;
     hipStream_t m, a, b;
+    // ext: a fork may ride on the producing kernel's own completion signal (ops.h, SIGGAN_LAUNCH_EV) instead of a marker packet
+    // behind it -- eager launches only (not under stream capture, not with the profiler's own events on the launch)
+    bool ext;
+    hipEvent_t tail_wait;        // d_backward_pass: one more event the main lane waits for where it is idle anyway (before its last join)
+    // the event to hand the producing launch as `done` (nullptr: fork_after records one the classic way)
+    hipEvent_t fork_event(hipStream_t to) { return (ext && to != m) ? next() : nullptr; }
+    void fork_after(hipStream_t to, hipEvent_t done) {      // `to` waits for the launch that was given `done` (and all before it on m)
+        if (to == m) return;
+        if (done) note(hipStreamWaitEvent(to, done, 0)); else fork(to);
+    }
     // with a communicator every lane event keeps its system-scope fence: peers read this device's gradient arena over xGMI
     hipEvent_t next() { hipEvent_t e = (c->comm ? c->ev_fenced : c->ev)[c->evi]; c->evi = (c->evi + 1) % siggan_ctx::NEV; return e; }
     void fork(hipStream_t to) {          // `to` waits for everything enqueued on m so far
@@ -662,7 +737,8 @@ static GConvArgs gconv_args(siggan_ctx* c) {
 // update) and raw pre-BN outputs kept for the backward pass; eval: BN folded into the epilogue.
 // z == nullptr: the latent batch is drawn inside the fc kernel from RNG stream rng_sid and left in z_out.
 static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, float* img, hipStream_t s,
-                           float* partial = nullptr, float* slab_k = nullptr, uint32_t rng_sid = 0, float* z_out = nullptr) {
+                           float* partial = nullptr, float* slab_k = nullptr, uint32_t rng_sid = 0, float* z_out = nullptr,
+                           hipEvent_t done = nullptr) {     // done: completion event of the pass' last launch
     if (!partial) partial = c->partial;
     char* const* const A = training ? c->g_a : c->g_ae;     // (fp32: the same buffers)
     // fc + BatchNorm1d + ReLU: one MFMA launch (fc.hip) whenever the shape allows, else the generic kernels
@@ -703,9 +779,9 @@ static void g_forward_pass(siggan_ctx* c, const float* z, int B, bool training, 
         }
     }
     if (training)
-        launch_final_fwd(c->dt, c->g_y[c->Lg], c->wfin_t, GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s, c->g_bn[c->Lg]);
+        launch_final_fwd(c->dt, c->g_y[c->Lg], c->wfin_t, GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s, c->g_bn[c->Lg], done);
     else
-        launch_final_fwd(c->dt, A[c->Lg], c->wfin_t, GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s);
+        launch_final_fwd(c->dt, A[c->Lg], c->wfin_t, GP(c, gi_fin_b(c)), img, B, c->S, c->gC[c->Lg], s, nullptr, done);
     c->ga_last_B = training ? B : 0;
 }
 
@@ -827,10 +903,22 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
         L.join(L.a);
         L.join(L.b);
     } else if (want_wgrad) {
+#ifndef NO_TAILMAIN
+        // fp32: lane a is still busy with the last (largest-K) weight gradient when the input-gradient chain ends, so the main
+        // lane is idle here: block 1's reductions run on it, and the waits for the lanes that ended earlier (lane b, the
+        // pipelined Generator forward) are processed in that window too -- every wait is a barrier packet of its own (~5 us
+        // each, one after the other), and only the one for lane a is left behind the last kernel
+        launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.m);
+        L.join(L.b);
+        if (L.tail_wait) L.wait(L.m, L.tail_wait);
+        L.join(L.a);
+#else
         L.fork(L.b);
         launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
         L.join(L.a);
         L.join(L.b);
+        if (L.tail_wait) L.wait(L.m, L.tail_wait);
+#endif
     }
     if (want_dimage)
         launch_conv1_dgrad_tanh(c->dt, dvp(1), c->d_w1t, x0, c->dpre, Bd, c->S, c->dC[1], L.m);
@@ -844,14 +932,17 @@ static void g_backward_pass(siggan_ctx* c, Lanes& L, const float* z, int B) {
     for (int l = Lg; l >= 1; --l) {
         const int Hi = 4 << (l - 1), Ho = 2 * Hi, Ci = c->gC[l - 1], Co = c->gC[l];
         const int64_t R = (int64_t)B * Ho * Ho;
+        // dy[l] is complete behind this block's BatchNorm backward: lane a's fork rides on that launch (four marker packets
+        // fewer on the lane every kernel of this pass waits on)
+        hipEvent_t const ef = L.fork_event(L.a);
         if (l == Lg) {   // final conv's input-gradient folded into this block's BatchNorm backward; its weight gradient rides in
                          // the same pass over y and its row sums stay on this lane (a 5 us kernel does not pay for a fork + join)
             launch_final_bwd_reduce(c->dt, c->dpre, c->wfin_t, c->g_y[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b, L.m);
             launch_final_bn_bwd_apply(c->dt, c->dpre, c->wfin_t, c->g_y[l], c->g_da[l], B, S, Co, c->g_bn[l], c->partial, c->partial_b,
-                                      GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m);
+                                      GG(c, gi_fin_w(c)), GG(c, gi_fin_b(c)), GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), L.m, ef);
         } else
-            launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m, pre_rows);
-        L.fork(L.a);                                       // dy[l] is complete on m here
+            launch_bn_bwd(c->dt, c->g_da[l], c->g_y[l], R, Co, c->g_bn[l], c->partial, GG(c, gi_bn_w(l)), GG(c, gi_bn_b(l)), 0, L.m, pre_rows, ef);
+        L.fork_after(L.a, ef);
         // weight gradient: small = block input a[l-1] (Hi), large = dy[l] (Ho)
         // (one fork per block; per two blocks measured the same, weight gradients on the main lane 2.5 % slower: DESIGN 4)
         WgradArgs w; memset(&w, 0, sizeof w); w.zeros = c->zeros; w.dt = c->dt;
@@ -979,7 +1070,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // there the early start measured 0.7 % slower (round 3) / 0.1 % faster with fence-free events (round 4: noise) -- its
     // BatchNorm / fc kernels take matrix-pipe time from the eval forward, which is on the step's critical lane.
     const bool spec_early = spec_fwd && c->dt != DT_F32;
-    hipEvent_t e_early = nullptr;
+    hipEvent_t e_early = nullptr, e_eval = nullptr;
     if (spec_early) { e_early = L.next(); L.record(e_early, L.m); }
     if (k.variant == SIGGAN_STEP_ABLATION) {
         // ablation_vanilla_gan_signatures.py:397-448: both nets in train mode and ONE Generator forward per iteration --
@@ -989,7 +1080,9 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         L.record(c->ev_gfwd, L.m);
         fake = c->img_g;
     } else {
-        g_forward_pass(c, k.has_z ? c->z : nullptr, B, false, c->img, L.m, nullptr, nullptr, 1, c->z);   // G.eval(), no grad (train...py:314-315)
+        // (nolane: the pipelined forward below needs nothing but this pass -- its fork rides on the last kernel here)
+        if (spec_fwd && !spec_early && nolane) e_eval = L.fork_event(c->s_c);
+        g_forward_pass(c, k.has_z ? c->z : nullptr, B, false, c->img, L.m, nullptr, nullptr, 1, c->z, e_eval);   // G.eval(), no grad (train...py:314-315)
     }
     if (spec_early) {       // (enqueued behind the eval forward: the critical lane's kernels reach the dispatcher first)
         L.wait(c->s_c, e_early);
@@ -1002,7 +1095,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // moves the BatchNorm running statistics and reuses the activation buffers; its own image / z /
     // scratch).  It forks HERE but is enqueued after D(fake), whose kernels the dispatcher should see first.
     hipEvent_t e_spec = nullptr;
-    if (spec_fwd && !spec_early) { e_spec = L.next(); L.record(e_spec, L.m); }
+    if (spec_fwd && !spec_early) { e_spec = e_eval; if (!e_spec) { e_spec = L.next(); L.record(e_spec, L.m); } }
     // the staged D(real) launch (lane c, previous G step) also drew THIS pass' dropout tables (dreal_noise2): the main lane
     // must be behind that lane before D(fake) reads them, not only before the backward pass reads the rows
     const bool join_early = k.pre_real == 2 && !c->dreal_joined && drop && c->dreal_noise2;
@@ -1015,10 +1108,14 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         g_forward_pass(c, k.has_zg ? c->z_g : nullptr, B, true, c->img_g, c->s_c, c->partial_c, c->slab_k2, 2, c->z_g);
         L.record(c->ev_gfwd, c->s_c);
     }
-    d_backward_pass(c, L, xreal, B, fake, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0}, 0, nullptr, k.coll != 0);
-    // 16-bit contexts: the pipelined forward ended long ago -- wait for it here, next to the two joins of this phase, instead of
-    // between the optimiser and the G step's first kernel
+    // the pipelined forward has ended by the time the weight gradients have: the main lane waits for it inside the backward
+    // pass' tail (fp32) / next to the two joins of this phase (16-bit), not between the optimiser and the G step's first kernel
     c->gfwd_joined = false;
+#ifndef NO_TAILMAIN
+    if (spec_fwd && c->dt == DT_F32) { L.tail_wait = c->ev_gfwd; c->gfwd_joined = true; }
+#endif
+    d_backward_pass(c, L, xreal, B, fake, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0}, 0, nullptr, k.coll != 0);
+    L.tail_wait = nullptr;
     if (spec_fwd && c->dt != DT_F32) { L.wait(L.m, c->ev_gfwd); c->gfwd_joined = true; }
 }
 
@@ -1032,8 +1129,9 @@ static void phase_g_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
         c->gfwd_joined = false;
         // trainer step: the first-block forward of the new images (rows [B, 2B), no dropout in this pass) rides in the launch
         // that re-packs D's weights -- it reads the raw block-1 weights, and the two would stand back to back on this lane
-        conv1_done = d_pack && k.variant != SIGGAN_STEP_ABLATION;
-        repack(c, L.m, L.m, false, d_pack, 0, conv1_done ? c->img_g : nullptr, B, B);
+        // (k.rode: both already happened in the D update's launch, k_adam_pack)
+        conv1_done = k.rode || (d_pack && k.variant != SIGGAN_STEP_ABLATION);
+        repack(c, L.m, L.m, false, d_pack, 0, (conv1_done && !k.rode) ? c->img_g : nullptr, B, B);
         zg = c->z_g; img = c->img_g;
     } else {
         L.fork(L.a);
@@ -1126,6 +1224,25 @@ static void phase_apply(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     }
     const bool guard = c->dt == DT_F16;                              // static gradient scale: skip the update on an overflow
     if (clip || guard) launch_grad_sumsq(g, n, c->dev, c->partial, L.m);
+    if (k.fused_t > 0.0 && k.pack) {
+        // ... and the same launch rebuilds what the next pass derives from the arena (weight packs, eval tables): no
+        // k_prepare between the update and the forward pass that follows it on the step's critical lane
+        ApTable t;
+        ApRide rd; memset(&rd, 0, sizeof rd);
+        if (k.ride) {      // the pending G step's first Discriminator block (siggan_step_begin's images; rows [B, 2B)) rides along
+            if (!c->gfwd_joined) { L.wait(L.m, c->ev_gfwd); c->gfwd_joined = true; }
+            const int64_t H = c->S >> 1;
+            rd.x = c->img_g; rd.out = c->d_a[1] + (size_t)((int64_t)k.ride * H * H * c->dC[1]) * c->es; rd.B = k.ride; rd.S = c->S;
+            rd.dt = c->dt; rd.slope = c->cfg.leaky_slope; rd.w_off = c->d_off[di_w(1)]; rd.b_off = c->d_off[di_b(1)];
+            rd.counter = (unsigned*)c->ride_ctr;
+        }
+        const bool ok = (which == 0 ? ap_table_g(c, t) : ap_table_d(c, t, k.ride ? k.ride * (c->S / 4) : 0)) &&
+            launch_adam_pack(t, p, g, m, v, c->dev, steps, nt, k.fused_t, k.lr, k.beta1, k.beta2, k.eps, gs, k.clip,
+                             k.mt + (which == 0 ? SIGGAN_M_G_GRAD_NORM : SIGGAN_M_D_GRAD_NORM), clip ? c->partial : nullptr,
+                             k.mt + (which == 0 ? SIGGAN_M_G_SKIPPED : SIGGAN_M_D_SKIPPED), BN_EPS, k.ride ? &rd : nullptr, L.m);
+        if (!ok) c->lane_err = hipErrorInvalidValue;                    // (apply_common checked the table: not reached)
+        return;
+    }
     if (k.fused_t > 0.0) {
         // ONE launch: the host knows the step count (apply_common), so the bias corrections are kernel arguments and
         // k_adam_prepare (a 5 us kernel plus a kernel boundary on the step's critical lane, twice per step) is not needed
@@ -1155,7 +1272,12 @@ static int run_phase(siggan_ctx* c, const PhaseKey& k, hipStream_t u) {
     if (graph && c->comm && k.phase >= 2) return fail(SIGGAN_E_STATE, "SIGGAN_MODE_GRAPH is not available with a communicator");
     if (graph && c->sn) return fail(SIGGAN_E_STATE, "SIGGAN_MODE_GRAPH is not available with spectral normalisation");
     if (!graph) {
-        Lanes L{c, u, overlap ? c->s_a : u, overlap ? c->s_b : u};
+#ifndef NO_EXTFORK
+        const bool ext = overlap && g_prof == nullptr;
+#else
+        const bool ext = false;
+#endif
+        Lanes L{c, u, overlap ? c->s_a : u, overlap ? c->s_b : u, ext, nullptr};
         run_phase_body(c, L, k);
         LAUNCHCHK();
         return lane_check(c);
@@ -1164,7 +1286,7 @@ static int run_phase(siggan_ctx* c, const PhaseKey& k, hipStream_t u) {
     for (auto& e : c->graphs)
         if (e.first == k) { exec = e.second; break; }
     if (!exec) {
-        Lanes L{c, c->s_m, overlap ? c->s_a : c->s_m, overlap ? c->s_b : c->s_m};
+        Lanes L{c, c->s_m, overlap ? c->s_a : c->s_m, overlap ? c->s_b : c->s_m, false, nullptr};
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(c->s_m, hipStreamCaptureModeRelaxed));
         run_phase_body(c, L, k);
@@ -1250,6 +1372,7 @@ extern "C" int siggan_d_forward(siggan_ctx* c, const float* x_dev, int32_t batch
     if (!x_dev || (!probs_dev && !features_dev)) return fail(SIGGAN_E_INVALID, "null tensor");
     hipStream_t s = (hipStream_t)stream;
     drop_dreal(c);                     // the activation rows of a D(real) forward started ahead of time are overwritten
+    c->conv1_rode = 0;                 // ... and those of a first-block forward the last D apply ran ahead
     if ((rc = settle(c, s))) return rc;
     if (c->sn) launch_sn_sigma(c->snt, training != 0, 2, SN_EPS, s);   // train(): one power iteration (u, v move), as torch's hook
     repack(c, s, s, c->g_dirty, c->sn || c->d_dirty, 2);
@@ -1371,12 +1494,26 @@ static int apply_common(siggan_ctx* c, int which, const siggan_hyper* hp, float*
             c->adam_t[wi] = (double)t0; c->adam_t_known[wi] = true;
         }
         k.fused_t = c->adam_t[wi] + 1.0;
+#ifndef NO_ADAM_PACK
+        ApTable probe;
+        k.pack = (which == 0 ? ap_table_g(c, probe) : ap_table_d(c, probe, 0)) ? 1 : 0;
+#ifndef NO_AP_RIDE
+        // trainer step with the G step's training forward already enqueued (siggan_step_begin): its first Discriminator block
+        // needs nothing but the updated block-1 weights -- it rides in the update's launch (phase_g_grads then skips it).
+        // fp32 only: 1.4201 -> 1.4105 ms; at bf16 the separate launch measured better (0.6216 vs 0.6245 ms)
+        if (which == 1 && k.pack && c->g_fwd_pending && c->variant != SIGGAN_STEP_ABLATION && g_prof == nullptr && c->dt == DT_F32)
+            k.ride = c->g_fwd_pending;
+#endif
+#endif
     } else {
         c->adam_t_known[wi] = false;
     }
     if ((rc = run_phase(c, k, s))) return rc;
     if (k.fused_t > 0.0) c->adam_t[wi] = k.fused_t;
-    if (which == 0) c->g_dirty = true; else c->d_dirty = true;
+    // (k.pack: the launch that updated the arena also rebuilt what is derived from it, with the running statistics as the
+    // G step's training forward left them)
+    if (which == 0) c->g_dirty = !k.pack; else c->d_dirty = !k.pack;
+    if (which == 1) c->conv1_rode = k.ride;
     c->pending = 0;
     return finish_metrics(c, metrics_dev, metrics_host, s);
 }
@@ -1414,6 +1551,8 @@ extern "C" int siggan_g_grads(siggan_ctx* c, int32_t batch, const float* z_dev, 
     PhaseKey k = make_key(c, 1, B, z_dev != nullptr, false, hp, metrics_dev);
     c->metrics_last = k.mt;
     k.spec_g = spec; k.variant = c->variant; k.has_masks = c->abl_masks;
+    k.rode = (spec && c->conv1_rode == B && !c->d_dirty) ? 1 : 0;
+    c->conv1_rode = 0;
     c->abl_masks = false;
     // a staged next batch: start its D(real) forward beside this Generator backward (own lane: eager overlap mode only)
     k.pre_real = c->staged_B == B && c->dreal_B == 0 && (c->mode & SIGGAN_MODE_OVERLAP) != 0 && (c->mode & SIGGAN_MODE_GRAPH) == 0 &&
