@@ -428,6 +428,37 @@ def test_execution_modes_are_bitwise_identical():
             assert mets == ref[1]
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_update_launch_leaves_the_packs_the_prepare_pass_would(dtype):
+    """k_adam_pack (the optimiser update that also writes the MFMA weight packs, the permuted one-channel weights and the
+    BatchNorm eval tables) against k_prepare: after pipelined steps -- whose updates wrote them, the D one with the next
+    pass' first block riding along at fp32 -- every pass that reads a pack must give the bits it gives once
+    siggan_params_changed has forced the prepare pass to rebuild them from the same arena: both forwards (forward packs,
+    tables, tap-major copies, the classifier's permutation) and the G step's gradients (both networks' input-gradient packs)."""
+    from hipcommon import cuda, make_engine
+    size, latent, batch = 64, 100, 16
+    reals = [cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"] + t))) for t in range(3)]
+    z = cuda(torch.from_numpy(I.gen_z(batch, latent, 91)))
+
+    def run(rebuild):
+        eng = make_engine(size, latent, batch, warm=True, dtype=dtype)
+        eng.seed(77)
+        for t in range(2):
+            eng.train_step(reals[t], clip=0.5 if t else None, next_real=reals[t + 1])
+        if rebuild:
+            eng.params_changed()
+        img = eng.g_forward(z, training=False).clone()
+        pr = eng.d_forward(reals[2]).clone()
+        eng.g_compute_grads(batch, z)
+        out = img, pr, eng.g_grads.clone(), eng.d_params.clone()
+        eng.close()
+        return out
+
+    a, b = run(False), run(True)
+    for name, x, y in zip(("generated images", "D(real) predictions", "G-step gradients", "D parameters"), a, b):
+        assert torch.equal(x, y), f"{name}: the packs written by the update launch differ from the prepare pass'"
+
+
 def test_staged_next_batch_is_bitwise_identical():
     """siggan_stage_real: D(real) of step t+1 runs beside the Generator backward of step t.  With the
     library's own RNG (z and dropout drawn on the device) the staged sequence must reproduce the
