@@ -67,9 +67,7 @@ static const int64_t PARTIAL_FLOATS = (int64_t)2 << 20;   // each of the three r
 // still release at agent scope, which is all a kernel on another lane of the same device needs.  The events in front of an
 // RCCL collective (peer devices read the gradient arena over xGMI) keep the fence: while a communicator exists the lanes use
 // the fenced ring (ev_fenced), and ev_sys / ev_ar are always fenced.
-#ifndef EV_FLAGS
 #define EV_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
-#endif
 #define ENTER(c)                                                     \
     if (!(c)) return fail(SIGGAN_E_INVALID, "null context");          \
     DevGuard dg_((c)->cfg.device);                                    \
@@ -903,7 +901,6 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
         L.join(L.a);
         L.join(L.b);
     } else if (want_wgrad) {
-#ifndef NO_TAILMAIN
         // fp32: lane a is still busy with the last (largest-K) weight gradient when the input-gradient chain ends, so the main
         // lane is idle here: block 1's reductions run on it, and the waits for the lanes that ended earlier (lane b, the
         // pipelined Generator forward) are processed in that window too -- every wait is a barrier packet of its own (~5 us
@@ -912,13 +909,6 @@ static void d_backward_pass(siggan_ctx* c, Lanes& L, const float* x0, int n0, co
         L.join(L.b);
         if (L.tail_wait) L.wait(L.m, L.tail_wait);
         L.join(L.a);
-#else
-        L.fork(L.b);
-        launch_conv1_wgrad(c->dt, dvp(1), x0, n0, x1, G_(di_w(1)), G_(di_b(1)), c->partial_b, Bd, c->S, c->dC[1], L.b);
-        L.join(L.a);
-        L.join(L.b);
-        if (L.tail_wait) L.wait(L.m, L.tail_wait);
-#endif
     }
     if (want_dimage)
         launch_conv1_dgrad_tanh(c->dt, dvp(1), c->d_w1t, x0, c->dpre, Bd, c->S, c->dC[1], L.m);
@@ -1111,9 +1101,7 @@ static void phase_d_grads(siggan_ctx* c, Lanes& L, const PhaseKey& k) {
     // the pipelined forward has ended by the time the weight gradients have: the main lane waits for it inside the backward
     // pass' tail (fp32) / next to the two joins of this phase (16-bit), not between the optimiser and the G step's first kernel
     c->gfwd_joined = false;
-#ifndef NO_TAILMAIN
     if (spec_fwd && c->dt == DT_F32) { L.tail_wait = c->ev_gfwd; c->gfwd_joined = true; }
-#endif
     d_backward_pass(c, L, xreal, B, fake, 2 * B, drop, true, false, BceSpec{B, k.ls, 0.f, k.mt, 0}, 0, nullptr, k.coll != 0);
     L.tail_wait = nullptr;
     if (spec_fwd && c->dt != DT_F32) { L.wait(L.m, c->ev_gfwd); c->gfwd_joined = true; }
@@ -1272,11 +1260,7 @@ static int run_phase(siggan_ctx* c, const PhaseKey& k, hipStream_t u) {
     if (graph && c->comm && k.phase >= 2) return fail(SIGGAN_E_STATE, "SIGGAN_MODE_GRAPH is not available with a communicator");
     if (graph && c->sn) return fail(SIGGAN_E_STATE, "SIGGAN_MODE_GRAPH is not available with spectral normalisation");
     if (!graph) {
-#ifndef NO_EXTFORK
         const bool ext = overlap && g_prof == nullptr;
-#else
-        const bool ext = false;
-#endif
         Lanes L{c, u, overlap ? c->s_a : u, overlap ? c->s_b : u, ext, nullptr};
         run_phase_body(c, L, k);
         LAUNCHCHK();
@@ -1494,17 +1478,13 @@ static int apply_common(siggan_ctx* c, int which, const siggan_hyper* hp, float*
             c->adam_t[wi] = (double)t0; c->adam_t_known[wi] = true;
         }
         k.fused_t = c->adam_t[wi] + 1.0;
-#ifndef NO_ADAM_PACK
         ApTable probe;
         k.pack = (which == 0 ? ap_table_g(c, probe) : ap_table_d(c, probe, 0)) ? 1 : 0;
-#ifndef NO_AP_RIDE
         // trainer step with the G step's training forward already enqueued (siggan_step_begin): its first Discriminator block
         // needs nothing but the updated block-1 weights -- it rides in the update's launch (phase_g_grads then skips it).
         // fp32 only: 1.4201 -> 1.4105 ms; at bf16 the separate launch measured better (0.6216 vs 0.6245 ms)
         if (which == 1 && k.pack && c->g_fwd_pending && c->variant != SIGGAN_STEP_ABLATION && g_prof == nullptr && c->dt == DT_F32)
             k.ride = c->g_fwd_pending;
-#endif
-#endif
     } else {
         c->adam_t_known[wi] = false;
     }
