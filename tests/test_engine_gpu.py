@@ -428,15 +428,14 @@ def test_execution_modes_are_bitwise_identical():
             assert mets == ref[1]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_update_launch_leaves_the_packs_the_prepare_pass_would(dtype):
+@pytest.mark.parametrize("dtype,size,latent,batch", [("f32", 64, 100, 16), ("bf16", 64, 100, 16), ("f32", 128, 128, 4)])
+def test_update_launch_leaves_the_packs_the_prepare_pass_would(dtype, size, latent, batch):
     """k_adam_pack (the optimiser update that also writes the MFMA weight packs, the permuted one-channel weights and the
     BatchNorm eval tables) against k_prepare: after pipelined steps -- whose updates wrote them, the D one with the next
     pass' first block riding along at fp32 -- every pass that reads a pack must give the bits it gives once
     siggan_params_changed has forced the prepare pass to rebuild them from the same arena: both forwards (forward packs,
     tables, tap-major copies, the classifier's permutation) and the G step's gradients (both networks' input-gradient packs)."""
     from hipcommon import cuda, make_engine
-    size, latent, batch = 64, 100, 16
     reals = [cuda(torch.from_numpy(I.gen_real(batch, size, SEED["real"] + t))) for t in range(3)]
     z = cuda(torch.from_numpy(I.gen_z(batch, latent, 91)))
 
